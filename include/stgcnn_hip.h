@@ -1,0 +1,166 @@
+/*
+ * stgcnn_hip.h -- C ABI of libstgcnn_hip.so: the MI355X (gfx950) Social-STGCNN hot path.
+ *
+ * The reference (GRatTWCU/Social-STGCNN) has no FFI: its hot path is Python on torch
+ * (model.py, utils.py, metrics.py).  This library is what a binding for that path binds
+ * (ctypes stub: social_stgcnn_amd/_lib.py).  Each entry point cites the
+ * reference code it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *  - plain pointers (DEVICE memory unless stated) and sizes; fp32 data, int32 counts.
+ *  - every function returns 0 on success, a negative STG_E* code for invalid arguments, or a
+ *    positive hipError_t; it never aborts, allocates nothing, does not synchronise the host
+ *    and keeps no mutable global state (re-entrant across streams).  Work is enqueued on
+ *    `stream` (a hipStream_t passed as void*; NULL = the default stream).
+ *  - a batch holds N scene-windows padded to V pedestrian slots; `num_peds` (int32[N], may be
+ *    NULL = all V valid) gives the real count V_i of each scene.  Slots >= V_i are ignored on
+ *    input and written as zeros on output.
+ *  - tensors are contiguous in the layouts named below unless explicit strides (in elements)
+ *    are part of the signature.
+ */
+#ifndef STGCNN_HIP_H
+#define STGCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STG_OK 0
+#define STG_EINVAL (-1)      /* bad size / null pointer / inconsistent arguments          */
+#define STG_EUNSUPPORTED (-2) /* configuration outside what the kernels are built for      */
+#define STG_ELDS (-3)        /* scene too large for the 160 KiB LDS of one CU             */
+
+#define STG_ABI_VERSION 1
+#define STG_MAX_BLOCKS 4     /* st_gcn blocks in one fused model                          */
+
+int stg_abi_version(void);
+/* Human-readable description of the last error raised on the calling thread. */
+const char *stg_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * R1/R2  utils.anorm + utils.seq_to_graph (utils.py:23-53) incl. networkx
+ *        normalized_laplacian_matrix (call site utils.py:48-50).
+ * rel:   relative displacements, element (n, v, c, t) at rel[n*rel_sn + v*rel_sv + c*rel_sc + t*rel_st]
+ *        (the reference layout (V,2,T) is rel_sv=2T, rel_sc=T, rel_st=1).
+ * nodes: out (N,T,V,2)  node features  V[s,h,:] = rel[h,:,s]            (may be NULL)
+ * adj:   out (N,T,V,V)  A[s,h,k] = 1/||rel_h - rel_k|| (0 if equal), A[s,h,h] = 1;
+ *        if normalize != 0 the symmetric normalised Laplacian D^-1/2 (D - A) D^-1/2.
+ */
+int stg_adj_build(const float *rel, int64_t rel_sn, int64_t rel_sv, int64_t rel_sc, int64_t rel_st,
+                  const int32_t *num_peds, int N, int V, int T, int normalize,
+                  float *nodes, float *adj, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * R3  the einsum of ConvTemporalGraphical.forward (model.py:67):
+ *        y[n,c,t,w] = sum_v x[n,c,t,v] * A[n,t,v,w]         ('nctv,ntvw->nctw')
+ * x (N,C,T,V) with strides; A (N,T,V,V) contiguous per scene with batch stride a_sn
+ * (a_sn = 0 shares one (T,V,V) adjacency over the batch: the reference's 'nctv,tvw->nctw').
+ * y (N,C,T,V) contiguous.  Backward: dx[n,c,t,v] = sum_w dy[n,c,t,w] * A[n,t,v,w] (A is data:
+ * no dA).
+ */
+int stg_spatial_agg_fwd(const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv,
+                        const float *adj, int64_t a_sn, const int32_t *num_peds,
+                        int N, int C, int T, int V, float *y, void *stream);
+int stg_spatial_agg_bwd(const float *dy, const float *adj, int64_t a_sn, const int32_t *num_peds,
+                        int N, int C, int T, int V, float *dx, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * R3/R4  nn.Conv2d(Cin, Cout, (kt,1), padding=(pad,0)) as built at model.py:55-62 and
+ *        model.py:116-122,135-139 (stride 1, dilation 1).
+ * x (N,Cin,T,V) strided, w (Cout,Cin,kt,1), b (Cout) or NULL, y (N,Cout,To,V), To = T+2*pad-kt+1.
+ * bwd: dx (N,Cin,T,V) (may be NULL), dw/db are ACCUMULATED into (+=) and must be zeroed by the
+ * caller (db may be NULL).
+ */
+int stg_conv_t_fwd(const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv,
+                   const float *w, const float *b, const int32_t *num_peds,
+                   int N, int Cin, int Cout, int T, int V, int kt, int pad, float *y, void *stream);
+int stg_conv_t_bwd(const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv,
+                   const float *w, const float *dy, const int32_t *num_peds,
+                   int N, int Cin, int Cout, int T, int V, int kt, int pad,
+                   float *dx, float *dw, float *db, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * R4/R5  st_gcn.forward (model.py:145-155) and social_stgcnn.forward (model.py:182-198) as ONE
+ *        scene-resident kernel per direction.
+ *
+ * Parameters live in one flat fp32 buffer in the reference's named_parameters() order
+ * (st_gcns.j: gcn.conv.weight, gcn.conv.bias, tcn.0.{weight,bias}, tcn.1.weight,
+ * tcn.2.{weight,bias}, tcn.3.{weight,bias}, [residual.0.{weight,bias}, residual.1.{weight,bias}],
+ * prelu.weight; tpcnns.k.{weight,bias}; tpcnn_ouput.{weight,bias}; prelus.k.weight), BatchNorm
+ * running statistics in a second flat buffer (per block: tcn.0 mean,var; tcn.3 mean,var;
+ * [residual.1 mean,var]).  stg_model_param_count()/stg_model_buffer_count() give the sizes.
+ */
+typedef struct {
+    int32_t n_stgcnn;      /* number of st_gcn blocks (model.py:163-166), 1..STG_MAX_BLOCKS      */
+    int32_t n_txpcnn;      /* 0 = no TXP-CNN (stand-alone st_gcn module); else model.py:168-172 */
+    int32_t c_in;          /* input_feat                                                        */
+    int32_t c_out;         /* output_feat                                                       */
+    int32_t t_obs;         /* seq_len                                                           */
+    int32_t t_pred;        /* pred_seq_len                                                      */
+    int32_t kt;            /* temporal kernel size (odd)                                        */
+    int32_t residual0;     /* first block: 0 none (residual=False), 1 identity, 2 conv+BN       */
+    int32_t use_mdn;       /* skip the block-final PReLU (model.py:152)                         */
+    int32_t bn_mode;       /* 0 eval (running stats), 1 train with per-scene statistics (the     */
+                           /* reference's N=1 training loop, train.py:36-77)                    */
+    float bn_eps;          /* 1e-5                                                              */
+    float bn_momentum;     /* 0.1                                                               */
+} stg_model_desc;
+
+int64_t stg_model_param_count(const stg_model_desc *d);
+int64_t stg_model_buffer_count(const stg_model_desc *d);
+/* Per-scene activation workspace (floats) the forward writes for the backward when save != 0. */
+int64_t stg_model_ws_floats(const stg_model_desc *d, int V);
+/* Per-scene batch statistics the forward emits in bn_mode 1: (N, stat_floats) =
+ * per block, per BatchNorm: mean[C], unbiased var[C].                                           */
+int64_t stg_model_stat_floats(const stg_model_desc *d);
+/* Number of partial-gradient slabs (of stg_model_param_count floats each) stg_model_bwd needs. */
+int64_t stg_model_bwd_slabs(const stg_model_desc *d, int N, int V);
+
+/* x (N,c_in,t_obs,V) strided; adj (N,t_obs,V,V), batch stride a_sn (0 = shared);
+ * y: (N,c_out,t_pred,V) when n_txpcnn>0, else the block output (N,c_out,t_obs,V).
+ * ws: N * stg_model_ws_floats floats or NULL (inference).  stats: N * stg_model_stat_floats or NULL. */
+int stg_model_fwd(const stg_model_desc *d, const float *params, const float *buffers,
+                  const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv,
+                  const float *adj, int64_t a_sn, const int32_t *num_peds, int N, int V,
+                  float *y, float *ws, float *stats, void *stream);
+/* dy like y.  grad_params (param_count) is OVERWRITTEN with the gradient summed over the batch;
+ * dx (N,c_in,t_obs,V) may be NULL.  slabs: stg_model_bwd_slabs * param_count floats scratch.    */
+int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buffers,
+                  const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv,
+                  const float *adj, int64_t a_sn, const int32_t *num_peds, int N, int V,
+                  const float *dy, const float *ws, float *slabs, float *grad_params, float *dx,
+                  void *stream);
+/* Sequential-fold update of the BatchNorm running statistics with the per-scene statistics of a
+ * batch, exactly as N successive reference forwards would (momentum update per scene,
+ * model.py:114,123,140; SURVEY 7 'BatchNorm semantics').  Scenes with num_peds[n] == 0 are skipped.
+ * nbt: HOST array of n_bn DEVICE pointers to the int64 num_batches_tracked counters (may be NULL);
+ * each is incremented by the number of non-empty scenes.                                          */
+int stg_bn_fold(const stg_model_desc *d, const float *stats, const int32_t *num_peds, int N,
+                float *buffers, int64_t *const *nbt, int n_bn, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * R6  metrics.bivariate_loss (metrics.py:84-113), batched: loss[n] = mean over (P, V_n) of
+ *     -log(clamp(pdf, 1e-20)).  pred element (n,f,p,v) at pred[n*p_sn + f*p_sf + p*p_sp + v*p_sv]
+ *     (f = mux,muy,log sx,log sy,atanh rho; the model output (N,5,P,V) is p_sf=P*V, p_sp=V, p_sv=1);
+ *     target (N,P,V,2) contiguous.  grad (N,5,P,V) contiguous receives d loss[n] / d pred (may be NULL).
+ */
+int stg_nll_fwd(const float *pred, int64_t p_sn, int64_t p_sf, int64_t p_sp, int64_t p_sv,
+                const float *target, const int32_t *num_peds, int N, int P, int V,
+                float *loss, float *grad, void *stream);
+/* out[n,f,p,v] = grad[n,f,p,v] * gloss[n]  (chain rule with the upstream gradient of loss[n]). */
+int stg_nll_bwd(const float *grad, const float *gloss, int N, int P, int V, float *out, void *stream);
+
+/* N3  optim.SGD(lr) step without momentum / weight decay (train.py:197): p -= lr * g.          */
+int stg_sgd_step(float *params, const float *grads, int64_t count, float lr, void *stream);
+
+/* Self-test helper: C(16x16) = A(16xK) * B(Kx16) through v_mfma_f32_16x16x4_f32 with the operand
+ * maps the TXP-CNN kernels rely on (K multiple of 4).                                           */
+int stg_selftest_mfma(const float *a, const float *b, int K, float *c, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STGCNN_HIP_H */

@@ -1,0 +1,59 @@
+// Layout of the flat parameter / buffer / workspace arrays shared by the fused scene-resident
+// kernels (model_fwd.hip, model_bwd.hip) and their host entry points.
+#pragma once
+#include "common.hpp"
+
+namespace stg {
+
+constexpr int kMaxTxp = 8;       // n_txpcnn supported by the fused kernels
+constexpr int kWsHdrPerBlock = 64;  // per-scene, per-block saved BatchNorm statistics (6*C <= 64)
+
+// Compile-time model family the fused kernels are instantiated for (reference defaults,
+// train.py:127-136): input_feat 2 -> output_feat 5, obs 8 -> pred 12, temporal kernel 3.
+struct Cfg {
+    static constexpr int CIN0 = 2, C = 5, T = 8, P = 12, KT = 3;
+};
+
+struct BlockLayout {
+    int32_t cin, residual;      // residual: 0 none, 1 identity, 2 conv+BN
+    // offsets (floats) into the flat parameter buffer, reference named_parameters() order
+    int32_t gcn_w, gcn_b, bn1_g, bn1_b, prelu1, tcn_w, tcn_b, bn2_g, bn2_b, res_w, res_b, bnr_g, bnr_b, prelu_o;
+    int32_t buf;                // running stats: bn1 mean,var | bn2 mean,var | [bnr mean,var], C floats each
+    int32_t stat;               // offset into the per-scene batch-statistics row (same order: mean, unbiased var)
+    int32_t n_bn;               // 2 or 3
+    // per-scene workspace: header slot (floats) and arrays in units of V floats
+    int32_t ws_hdr;             // mean1,rstd1,mean2,rstd2,meanr,rstdr (C each)
+    int32_t ws_ax, ws_cs, ws_g, ws_h2, ws_s;
+};
+
+struct ModelLayout {
+    int32_t n_blocks, n_txp, L;     // L = hidden TXP layers actually used = max(1, n_txp-1), 0 if n_txp==0
+    BlockLayout blk[STG_MAX_BLOCKS];
+    int32_t txp_w[kMaxTxp], txp_b[kMaxTxp], out_w, out_b, prelus;
+    int32_t n_params, n_buffers, stat_floats;
+    int32_t ws_hdr_floats;          // fixed part of the per-scene workspace
+    int32_t ws_a[kMaxTxp + 1];      // a_0 (T*C rows) .. a_L (P*C rows), units of V floats
+    int32_t ws_z[kMaxTxp];          // z_0 .. z_{L-1}
+    int32_t ws_units;               // total units of V floats
+    int32_t use_mdn, bn_mode;
+    float eps, momentum;
+};
+
+// Fills `lay` from the public descriptor; returns STG_OK or an error code (message in last_error).
+int make_layout(const stg_model_desc *d, ModelLayout *lay);
+
+inline int64_t ws_floats_per_scene(const ModelLayout &l, int V) {
+    return (int64_t)l.ws_hdr_floats + (int64_t)l.ws_units * V;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS geometry of one padded TXP plane set: rows = C + 2, row stride SW = vi + 2, channel stride SC
+// chosen == 16 (mod 32) so the four K-lanes groups of a 16x16x4 B-operand read hit disjoint banks.
+__host__ __device__ inline int txp_sw(int vi) { return vi + 2; }
+__host__ __device__ inline int txp_sc(int vi) {
+    const int raw = (Cfg::C + 2) * (vi + 2);
+    return raw + ((16 - (raw & 31)) & 31);
+}
+
+}  // namespace stg

@@ -1,0 +1,99 @@
+// nll: metrics.bivariate_loss (metrics.py:84-113), batched and fused with its gradient.
+//   loss[n] = mean_{p<P, v<V_n} -log(max(pdf, 1e-20)),
+//   pdf = exp(-z / (2(1-rho^2))) / (2 pi sx sy sqrt(1-rho^2)),  z as metrics.py:97.
+// One workgroup per scene; the forward value follows the reference's operation order; the gradient
+// is the closed form of d(-log pdf)/d(pred) and is zero where the clamp is active.
+#include "common.hpp"
+
+namespace stg {
+
+__global__ __launch_bounds__(256) void nll_fwd_kernel(
+    const float *__restrict__ pred, int64_t p_sn, int64_t p_sf, int64_t p_sp, int64_t p_sv,
+    const float *__restrict__ target, const int32_t *__restrict__ num_peds, int P, int V,
+    float *__restrict__ loss, float *__restrict__ grad) {
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    int vi = num_peds ? num_peds[n] : V;
+    vi = vi < 0 ? 0 : (vi > V ? V : vi);
+    const float *pn = pred + n * p_sn;
+    const float *tn = target + (int64_t)n * P * V * 2;
+    float *gn = grad ? grad + (int64_t)n * 5 * P * V : nullptr;
+    const float inv_cnt = vi > 0 ? 1.0f / (float)(P * vi) : 0.f;
+    float acc = 0.f;
+    for (int e = tid; e < P * V; e += blockDim.x) {
+        const int p = e / V, v = e - p * V;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
+        if (v < vi) {
+            const float *q = pn + p * p_sp + v * p_sv;
+            const float mx = q[0], my = q[p_sf], a = q[2 * p_sf], b = q[3 * p_sf], c = q[4 * p_sf];
+            const float2 tg = *reinterpret_cast<const float2 *>(tn + (int64_t)e * 2);
+            const float dx = tg.x - mx, dy = tg.y - my;
+            const float sx = expf(a), sy = expf(b), rho = tanhf(c);
+            const float sxsy = sx * sy;
+            const float ux = dx / sx, uy = dy / sy;
+            const float cross = (rho * dx * dy) / sxsy;
+            const float z = ux * ux + uy * uy - 2.f * cross;
+            const float om = 1.f - rho * rho;
+            const float num = expf(-z / (2.f * om));
+            const float den = 2.f * 3.14159265358979323846f * (sxsy * sqrtf(om));
+            const float pdf = num / den;
+            const bool live = pdf > 1e-20f;            // torch.clamp(min=eps) passes gradient iff x > eps
+            acc += -logf(live ? pdf : 1e-20f);
+            if (gn && live) {
+                const float qq = (dx * dy) / sxsy;
+                g0 = -(dx / (sx * sx) - rho * dy / sxsy) / om;
+                g1 = -(dy / (sy * sy) - rho * dx / sxsy) / om;
+                g2 = 1.f - (ux * ux - rho * qq) / om;
+                g3 = 1.f - (uy * uy - rho * qq) / om;
+                g4 = -qq + z * rho / om - rho;
+            }
+        }
+        if (gn) {
+            const int64_t pv = (int64_t)P * V;
+            gn[e] = g0 * inv_cnt;
+            gn[pv + e] = g1 * inv_cnt;
+            gn[2 * pv + e] = g2 * inv_cnt;
+            gn[3 * pv + e] = g3 * inv_cnt;
+            gn[4 * pv + e] = g4 * inv_cnt;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) loss[n] = (red[0] + red[1] + red[2] + red[3]) * inv_cnt;
+}
+
+__global__ void nll_bwd_kernel(const float *__restrict__ grad, const float *__restrict__ gloss, int64_t per_scene,
+                               int64_t total, float *__restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < total) out[i] = grad[i] * gloss[i / per_scene];
+}
+
+}  // namespace stg
+
+extern "C" {
+
+int stg_nll_fwd(const float *pred, int64_t p_sn, int64_t p_sf, int64_t p_sp, int64_t p_sv, const float *target,
+                const int32_t *num_peds, int N, int P, int V, float *loss, float *grad, void *stream) {
+    STG_REQUIRE(pred && target && loss, STG_EINVAL, "stg_nll_fwd: null pointer");
+    STG_REQUIRE(N >= 0 && P > 0 && V > 0, STG_EINVAL, "stg_nll_fwd: bad sizes N=%d P=%d V=%d", N, P, V);
+    if (N == 0) return STG_OK;
+    hipLaunchKernelGGL(stg::nll_fwd_kernel, dim3(N), dim3(256), 0, stg::as_stream(stream), pred, p_sn, p_sf, p_sp,
+                       p_sv, target, num_peds, P, V, loss, grad);
+    STG_LAUNCH_CHECK("stg_nll_fwd");
+    return STG_OK;
+}
+
+int stg_nll_bwd(const float *grad, const float *gloss, int N, int P, int V, float *out, void *stream) {
+    STG_REQUIRE(grad && gloss && out, STG_EINVAL, "stg_nll_bwd: null pointer");
+    STG_REQUIRE(N >= 0 && P > 0 && V > 0, STG_EINVAL, "stg_nll_bwd: bad sizes");
+    if (N == 0) return STG_OK;
+    const int64_t per_scene = (int64_t)5 * P * V, total = per_scene * N;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(stg::nll_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stg::as_stream(stream), grad, gloss,
+                       per_scene, total, out);
+    STG_LAUNCH_CHECK("stg_nll_bwd");
+    return STG_OK;
+}
+
+}  // extern "C"

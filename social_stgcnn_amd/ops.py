@@ -1,0 +1,304 @@
+"""Host-side operator layer: torch.autograd.Functions over the C ABI (include/stgcnn_hip.h).
+
+Every function here launches hand-written HIP kernels on the current torch stream and
+raises if the library or a GPU tensor is missing -- there is no eager fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ModelDesc, check, lib, peds_arg, ptr, require_gpu, stream_ptr
+
+
+def _adj_layout(adj, n, t, v):
+    """adjacency (T,V,V) shared or (N,T,V,V) -> (contiguous-per-scene tensor, batch stride)."""
+    if adj.dim() == 3:
+        if tuple(adj.shape) != (t, v, v):
+            raise ValueError("adjacency %s does not match x (T=%d, V=%d)" % (tuple(adj.shape), t, v))
+        return adj.contiguous(), 0
+    if adj.dim() == 4:
+        if tuple(adj.shape) != (n, t, v, v):
+            raise ValueError("adjacency %s does not match x (N=%d, T=%d, V=%d)" % (tuple(adj.shape), n, t, v))
+        if adj.stride()[1:] != (v * v, v, 1):
+            adj = adj.contiguous()
+        return adj, adj.stride(0)
+    raise ValueError("adjacency must be (T,V,V) or (N,T,V,V), got %d dims" % adj.dim())
+
+
+# --------------------------------------------------------------------------------------------
+# R1/R2 adjacency build
+# --------------------------------------------------------------------------------------------
+def adj_build(seq_rel, num_peds=None, normalize=True):
+    """seq_rel (N,V,2,T) fp32 device tensor (any strides) -> nodes (N,T,V,2), adj (N,T,V,V).
+    Counterpart of utils.seq_to_graph (utils.py:29-53)."""
+    require_gpu(seq_rel)
+    _lib.as_f32(seq_rel, "seq_rel")
+    n, v, c, t = seq_rel.shape
+    if c != 2:
+        raise ValueError("seq_rel must be (N,V,2,T)")
+    peds = peds_arg(num_peds, n, seq_rel.device)
+    nodes = torch.empty((n, t, v, 2), device=seq_rel.device, dtype=torch.float32)
+    adj = torch.empty((n, t, v, v), device=seq_rel.device, dtype=torch.float32)
+    sn, sv, sc, st = seq_rel.stride()
+    check(lib().stg_adj_build(ptr(seq_rel), sn, sv, sc, st, ptr(peds), n, v, t, 1 if normalize else 0,
+                              ptr(nodes), ptr(adj), stream_ptr()), "stg_adj_build")
+    return nodes, adj
+
+
+# --------------------------------------------------------------------------------------------
+# R3 spatial aggregation einsum('nctv,ntvw->nctw')
+# --------------------------------------------------------------------------------------------
+class _SpatialAgg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, adj, num_peds):
+        require_gpu(x, adj)
+        _lib.as_f32(x, "x")
+        _lib.as_f32(adj, "adj")
+        n, c, t, v = x.shape
+        adj_c, a_sn = _adj_layout(adj, n, t, v)
+        peds = peds_arg(num_peds, n, x.device)
+        y = torch.empty((n, c, t, v), device=x.device, dtype=torch.float32)
+        sn, sc, st, sv = x.stride()
+        check(lib().stg_spatial_agg_fwd(ptr(x), sn, sc, st, sv, ptr(adj_c), a_sn, ptr(peds), n, c, t, v, ptr(y),
+                                        stream_ptr()), "stg_spatial_agg_fwd")
+        ctx.save_for_backward(adj_c, peds if peds is not None else torch.empty(0))
+        ctx.a_sn = a_sn
+        ctx.has_peds = peds is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        adj_c, peds = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c, t, v = dy.shape
+        dx = torch.empty_like(dy)
+        check(lib().stg_spatial_agg_bwd(ptr(dy), ptr(adj_c), ctx.a_sn, ptr(peds) if ctx.has_peds else None, n, c, t,
+                                        v, ptr(dx), stream_ptr()), "stg_spatial_agg_bwd")
+        return dx, None, None
+
+
+def spatial_agg(x, adj, num_peds=None):
+    """y[n,c,t,w] = sum_v x[n,c,t,v] A[n,t,v,w]   (model.py:67); adj (T,V,V) or (N,T,V,V)."""
+    return _SpatialAgg.apply(x, adj, num_peds)
+
+
+# --------------------------------------------------------------------------------------------
+# temporal / 1x1 convolution (kt x 1)
+# --------------------------------------------------------------------------------------------
+class _ConvT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad, num_peds):
+        require_gpu(x, weight, bias)
+        _lib.as_f32(x, "x")
+        n, cin, t, v = x.shape
+        cout, cin_w, kt, kw = weight.shape
+        if cin_w != cin or kw != 1:
+            raise ValueError("weight %s does not match input channels %d" % (tuple(weight.shape), cin))
+        to = t + 2 * pad - kt + 1
+        peds = peds_arg(num_peds, n, x.device)
+        w = weight.contiguous()
+        b = bias.contiguous() if bias is not None else None
+        y = torch.empty((n, cout, to, v), device=x.device, dtype=torch.float32)
+        sn, sc, st, sv = x.stride()
+        check(lib().stg_conv_t_fwd(ptr(x), sn, sc, st, sv, ptr(w), ptr(b), ptr(peds), n, cin, cout, t, v, kt, pad,
+                                   ptr(y), stream_ptr()), "stg_conv_t_fwd")
+        ctx.save_for_backward(x, w, peds if peds is not None else torch.empty(0))
+        ctx.has_peds = peds is not None
+        ctx.has_bias = bias is not None
+        ctx.pad = pad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, peds = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, cin, t, v = x.shape
+        cout, _, kt, _ = w.shape
+        dx = torch.empty((n, cin, t, v), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros_like(w)
+        db = torch.zeros(cout, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        sn, sc, st, sv = x.stride()
+        check(lib().stg_conv_t_bwd(ptr(x), sn, sc, st, sv, ptr(w), ptr(dy), ptr(peds) if ctx.has_peds else None, n,
+                                   cin, cout, t, v, kt, ctx.pad, ptr(dx), ptr(dw), ptr(db), stream_ptr()),
+              "stg_conv_t_bwd")
+        return dx, dw, db, None, None
+
+
+def conv_t(x, weight, bias, pad=0, num_peds=None):
+    """nn.Conv2d(Cin, Cout, (kt,1), padding=(pad,0)) forward/backward (model.py:55-62)."""
+    return _ConvT.apply(x, weight, bias, pad, num_peds)
+
+
+# --------------------------------------------------------------------------------------------
+# R4/R5 fused st_gcn / social_stgcnn
+# --------------------------------------------------------------------------------------------
+class FlatPack:
+    """Keeps a list of tensors as views of ONE flat fp32 device buffer (the layout the fused
+    kernels read).  `ensure()` is cheap when nothing moved; it re-packs after .to(), a
+    load_state_dict that replaced storage, or a child module packing itself."""
+
+    def __init__(self):
+        self.flat = None
+
+    def ensure(self, tensors):
+        total = sum(t.numel() for t in tensors)
+        dev = tensors[0].device
+        flat = self.flat
+        ok = flat is not None and flat.device == dev and flat.numel() == total
+        if ok:
+            base = flat.data_ptr()
+            off = 0
+            for t in tensors:
+                if t.data_ptr() != base + 4 * off or not t.is_contiguous():
+                    ok = False
+                    break
+                off += t.numel()
+        if not ok:
+            flat = torch.empty(total, device=dev, dtype=torch.float32)
+            off = 0
+            with torch.no_grad():
+                for t in tensors:
+                    n = t.numel()
+                    flat[off:off + n].copy_(t.detach().reshape(-1))
+                    t.data = flat[off:off + n].view(t.shape)
+                    off += n
+            self.flat = flat
+        return self.flat
+
+
+def make_desc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, use_mdn, training,
+              eps=1e-5, momentum=0.1):
+    return ModelDesc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, 1 if use_mdn else 0,
+                     1 if training else 0, eps, momentum)
+
+
+class _FusedModel(torch.autograd.Function):
+    """x (N,Cin,T,V), adj -> y.  Extra (non-differentiable) arguments carry the packed buffers."""
+
+    @staticmethod
+    def forward(ctx, x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, *params):
+        require_gpu(x, adj, flat_params, flat_buffers)
+        _lib.as_f32(x, "x")
+        _lib.as_f32(adj, "adj")
+        L = lib()
+        n, cin, t, v = x.shape
+        if cin != desc.c_in or t != desc.t_obs:
+            raise ValueError("input (N,%d,%d,V) does not match the model (input_feat=%d, seq_len=%d)"
+                             % (cin, t, desc.c_in, desc.t_obs))
+        adj_c, a_sn = _adj_layout(adj, n, t, v)
+        peds = peds_arg(num_peds, n, x.device)
+        training = desc.bn_mode == 1
+        need_grad = any(ctx.needs_input_grad)
+        out_t = desc.t_pred if desc.n_txpcnn > 0 else desc.t_obs
+        y = torch.empty((n, desc.c_out, out_t, v), device=x.device, dtype=torch.float32)
+        ws = None
+        if need_grad:
+            wsf = L.stg_model_ws_floats(ctypes.byref(desc), v)
+            if wsf < 0:
+                check(int(wsf), "stg_model_ws_floats")
+            ws = torch.empty(n * wsf, device=x.device, dtype=torch.float32)
+        stats = None
+        if training:
+            sf = L.stg_model_stat_floats(ctypes.byref(desc))
+            stats = torch.empty((n, max(int(sf), 1)), device=x.device, dtype=torch.float32)
+        sn, sc, st, sv = x.stride()
+        check(L.stg_model_fwd(ctypes.byref(desc), ptr(flat_params), ptr(flat_buffers), ptr(x), sn, sc, st, sv,
+                              ptr(adj_c), a_sn, ptr(peds), n, v, ptr(y), ptr(ws), ptr(stats), stream_ptr()),
+              "stg_model_fwd")
+        if training:
+            arr = (ctypes.c_void_p * len(nbt))(*[b.data_ptr() for b in nbt])
+            # nbt[k] counts forwards of BatchNorm k; buffers are interleaved (mean, var) per BatchNorm, the
+            # kernel bumps counter i for statistic row i < len(nbt): pass one pointer per BatchNorm.
+            check(L.stg_bn_fold(ctypes.byref(desc), ptr(stats), ptr(peds), n, ptr(flat_buffers), arr, len(nbt),
+                                stream_ptr()), "stg_bn_fold")
+        ctx.desc = desc
+        ctx.a_sn = a_sn
+        ctx.dead = dead
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.flat_params = flat_params
+        ctx.flat_buffers = flat_buffers
+        ctx.tensors = (x, adj_c, peds, ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = lib()
+        desc = ctx.desc
+        x, adj_c, peds, ws = ctx.tensors
+        if ws is None:
+            raise RuntimeError("backward through a forward that saved no activations")
+        dy = dy.contiguous()
+        n, cin, t, v = x.shape
+        np_ = int(L.stg_model_param_count(ctypes.byref(desc)))
+        n_slabs = L.stg_model_bwd_slabs(ctypes.byref(desc), n, v)
+        if n_slabs < 0:
+            check(int(n_slabs), "stg_model_bwd_slabs")
+        slabs = torch.empty(int(n_slabs) * np_, device=x.device, dtype=torch.float32)
+        grad = torch.empty(np_, device=x.device, dtype=torch.float32)
+        dx = torch.empty((n, cin, t, v), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        sn, sc, st, sv = x.stride()
+        check(L.stg_model_bwd(ctypes.byref(desc), ptr(ctx.flat_params), ptr(ctx.flat_buffers), ptr(x), sn, sc, st,
+                              sv, ptr(adj_c), ctx.a_sn, ptr(peds), n, v, ptr(dy), ptr(ws), ptr(slabs), ptr(grad),
+                              ptr(dx), stream_ptr()), "stg_model_bwd")
+        grads = []
+        off = 0
+        for i, shp in enumerate(ctx.shapes):
+            cnt = 1
+            for s in shp:
+                cnt *= s
+            grads.append(None if i in ctx.dead else grad[off:off + cnt].view(shp))
+            off += cnt
+        ctx.flat_grad = grad
+        return (dx, None, None, None, None, None, None, None, *grads)
+
+
+def fused_model(x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, params):
+    return _FusedModel.apply(x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, *params)
+
+
+# --------------------------------------------------------------------------------------------
+# R6 bivariate Gaussian NLL
+# --------------------------------------------------------------------------------------------
+class _BivariateNLL(torch.autograd.Function):
+    """pred (N,P,V,5) (any strides), target (N,P,V,2) -> loss (N,)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, num_peds):
+        require_gpu(pred, target)
+        _lib.as_f32(pred, "V_pred")
+        n, p, v, f = pred.shape
+        if f != 5 or tuple(target.shape) != (n, p, v, 2):
+            raise ValueError("bivariate_loss: V_pred (..,P,V,5) / V_trgt (..,P,V,2) expected, got %s / %s"
+                             % (tuple(pred.shape), tuple(target.shape)))
+        target = target.to(torch.float32).contiguous()
+        peds = peds_arg(num_peds, n, pred.device)
+        loss = torch.empty(n, device=pred.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0]
+        grad = torch.empty((n, 5, p, v), device=pred.device, dtype=torch.float32) if need else None
+        sn, sp, sv, sf = pred.stride()
+        check(lib().stg_nll_fwd(ptr(pred), sn, sf, sp, sv, ptr(target), ptr(peds), n, p, v, ptr(loss), ptr(grad),
+                                stream_ptr()), "stg_nll_fwd")
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        grad = ctx.grad
+        n, _, p, v = grad.shape
+        gloss = gloss.to(torch.float32).contiguous()
+        out = torch.empty_like(grad)
+        check(lib().stg_nll_bwd(ptr(grad), ptr(gloss), n, p, v, ptr(out), stream_ptr()), "stg_nll_bwd")
+        # (N,5,P,V) buffer viewed in the caller's (N,P,V,5) index order
+        return out.permute(0, 2, 3, 1), None, None
+
+
+def bivariate_nll(pred, target, num_peds=None):
+    return _BivariateNLL.apply(pred, target, num_peds)
+
+
+def sgd_step(flat_params, flat_grads, lr):
+    """p -= lr * g on the flat buffers (train.py:197 SGD without momentum)."""
+    require_gpu(flat_params, flat_grads)
+    check(lib().stg_sgd_step(ptr(flat_params), ptr(flat_grads), flat_params.numel(), float(lr), stream_ptr()),
+          "stg_sgd_step")

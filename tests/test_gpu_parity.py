@@ -1,0 +1,425 @@
+"""GPU parity tests (-m gpu): every HIP entry point, called through the C ABI (ctypes),
+against the CPU oracle (oracle/stgcnn_oracle.py) and the reference-generated fixtures in
+tests/golden/.  Tolerances: fp32; the north-star bar for the bivariate parameters is 1e-4
+absolute, the tests hold the kernels to 2e-5 or tighter and state each bound where it is used."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+VS = (2, 3, 5, 8, 17, 32, 57)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda", 0)
+
+
+def _oracle():
+    from oracle import stgcnn_oracle as O
+    return O
+
+
+def _state(npz, prefix=""):
+    return {k[len(prefix):]: torch.from_numpy(np.array(npz[k])) for k in npz.files if k.startswith(prefix)}
+
+
+def _model(dev, state=None, seed=None, **kw):
+    from social_stgcnn_amd.model import social_stgcnn
+    cfg = dict(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3, pred_seq_len=12)
+    cfg.update(kw)
+    if seed is not None:
+        torch.manual_seed(seed)
+    m = social_stgcnn(**cfg)
+    if state is not None:
+        m.load_state_dict(state)
+    return m.to(dev)
+
+
+def _maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+# ------------------------------------------------------------------------------------------
+def test_library_loaded_and_mfma_operand_maps(dev):
+    from social_stgcnn_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    for K in (4, 72, 108):
+        a = rng.standard_normal((16, K)).astype(np.float32)
+        b = rng.standard_normal((K, 16)).astype(np.float32)      # asymmetric on purpose
+        ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+        tc = torch.zeros(16, 16, device=dev)
+        _lib.check(L.stg_selftest_mfma(_lib.ptr(ta), _lib.ptr(tb), K, _lib.ptr(tc), _lib.stream_ptr()), "selftest")
+        ref = a.astype(np.float64) @ b.astype(np.float64)
+        assert _maxdiff(tc.cpu().numpy(), ref) < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("v", VS + ("tie",))
+def test_adj_build_golden(dev, v):
+    """R1/R2 against the reference's seq_to_graph output (fixture) -- bound 1e-6 absolute."""
+    from social_stgcnn_amd.utils import seq_to_graph
+    g = load_golden("adj_cases.npz")
+    rel = torch.from_numpy(g["rel_%s" % v])
+    nodes, adj = seq_to_graph(None, rel, True)            # CPU in -> CPU out, computed on the GPU
+    assert nodes.device.type == "cpu"
+    assert np.array_equal(nodes.numpy(), g["nodes_%s" % v])
+    assert _maxdiff(adj.numpy(), g["lap_%s" % v]) < 1e-6
+    assert np.all(adj.numpy()[0] == 0)
+
+
+def test_adj_build_batched_ragged(dev):
+    """padded batch with num_peds: padded rows/cols are zero, valid block == per-scene result;
+    raw (un-normalised) adjacency has unit diagonal and the exact ==0 rule."""
+    from social_stgcnn_amd import ops
+    O = _oracle()
+    g = load_golden("adj_cases.npz")
+    vs = [2, 17, 5, 57, 32, 3, 8]
+    vmax = 60
+    rel = torch.zeros(len(vs), vmax, 2, 8)
+    for i, v in enumerate(vs):
+        rel[i, :v] = torch.from_numpy(g["rel_%d" % v])
+    rel[:, 58:] = 7.0        # garbage in padded slots must be ignored
+    nodes, adj = ops.adj_build(rel.to(dev), num_peds=vs, normalize=True)
+    nodes, adj = nodes.cpu().numpy(), adj.cpu().numpy()
+    for i, v in enumerate(vs):
+        assert _maxdiff(adj[i, :, :v, :v], g["lap_%d" % v]) < 1e-6
+        assert np.all(adj[i, :, v:, :] == 0) and np.all(adj[i, :, :, v:] == 0)
+        assert np.array_equal(nodes[i, :, :v], g["nodes_%d" % v]) and np.all(nodes[i, :, v:] == 0)
+    _, raw = ops.adj_build(torch.from_numpy(g["rel_tie"]).unsqueeze(0).to(dev), normalize=False)
+    raw = raw[0].cpu().numpy()
+    assert np.all(raw[:, np.arange(4), np.arange(4)] == 1)
+    assert raw[2, 0, 1] == 0 and raw[2, 1, 0] == 0          # equal velocities -> no edge
+    # odd V exercises the scalar-store path
+    rel5 = torch.from_numpy(g["rel_5"]).unsqueeze(0)
+    _, a5 = ops.adj_build(rel5.to(dev))
+    assert _maxdiff(a5[0].cpu().numpy(), O.seq_to_graph_np(g["rel_5"])[1]) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,c,v,shared", [(3, 5, 32, False), (2, 2, 7, False), (4, 5, 57, True), (1, 11, 12, False)])
+def test_spatial_agg(dev, n, c, v, shared):
+    """R3 einsum('nctv,ntvw->nctw') forward and dx; fp32 reference = torch.einsum on the CPU, 2e-5."""
+    from social_stgcnn_amd import ops
+    g = torch.Generator().manual_seed(v)
+    x = torch.randn(n, v, c, 8, generator=g).permute(0, 2, 3, 1)       # non-contiguous like train.py:48
+    A = torch.randn(8, v, v, generator=g) if shared else torch.randn(n, 8, v, v, generator=g)
+    peds = None if shared else [max(1, v - 3 * i) for i in range(n)]
+    xr = x.clone().requires_grad_(True)
+    eq = 'nctv,tvw->nctw' if shared else 'nctv,ntvw->nctw'
+    if peds is not None:
+        # reference on the valid block of every scene only
+        ref = torch.zeros(n, c, 8, v)
+        parts = []
+        for i, p in enumerate(peds):
+            parts.append(torch.einsum('ctv,tvw->ctw', xr[i, :, :, :p], A[i, :, :p, :p]))
+        gy = torch.randn(n, c, 8, v, generator=g)
+        loss = sum((parts[i] * gy[i, :, :, :p]).sum() for i, p in enumerate(peds))
+        loss.backward()
+        for i, p in enumerate(peds):
+            ref[i, :, :, :p] = parts[i].detach()
+    else:
+        ref_t = torch.einsum(eq, xr, A)
+        gy = torch.randn(n, c, 8, v, generator=g)
+        (ref_t * gy).sum().backward()
+        ref = ref_t.detach()
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.spatial_agg(xd, A.to(dev), peds)
+    (y * gy.to(dev)).sum().backward()
+    scale = max(1.0, float(ref.abs().max()))
+    assert _maxdiff(y.detach().cpu().numpy(), ref.numpy()) < 2e-5 * scale
+    gref = xr.grad.numpy()
+    assert _maxdiff(xd.grad.cpu().numpy(), gref) < 2e-5 * max(1.0, np.abs(gref).max())
+
+
+@pytest.mark.parametrize("cin,cout,kt,pad,v", [(2, 5, 1, 0, 9), (5, 5, 3, 1, 32), (3, 7, 3, 0, 5)])
+def test_conv_t(dev, cin, cout, kt, pad, v):
+    from social_stgcnn_amd import ops
+    g = torch.Generator().manual_seed(cin * 10 + kt)
+    x = torch.randn(3, cin, 8, v, generator=g)
+    w = torch.randn(cout, cin, kt, 1, generator=g) * 0.3
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, wr, br, padding=(pad, 0))
+    gy = torch.randn(ref.shape, generator=g)
+    (ref * gy).sum().backward()
+    xd, wd, bd = [t.to(dev).requires_grad_(True) for t in (x, w, b)]
+    y = ops.conv_t(xd, wd, bd, pad)
+    (y * gy.to(dev)).sum().backward()
+    assert _maxdiff(y.detach().cpu().numpy(), ref.detach().numpy()) < 2e-5
+    assert _maxdiff(xd.grad.cpu().numpy(), xr.grad.numpy()) < 2e-5
+    assert _maxdiff(wd.grad.cpu().numpy(), wr.grad.numpy()) < 1e-4
+    assert _maxdiff(bd.grad.cpu().numpy(), br.grad.numpy()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------
+def test_bivariate_loss_golden(dev):
+    """R6 value and gradient against the reference fixture (incl. clamp-active element)."""
+    from social_stgcnn_amd.metrics import bivariate_loss
+    g = load_golden("loss_cases.npz")
+    # hand the kernel the same strided view the training loop produces (train.py:52)
+    vp_store = torch.from_numpy(g["vpred"]).permute(2, 0, 1).contiguous().to(dev)       # (5,P,V)
+    vp_store.requires_grad_(True)
+    vp = vp_store.permute(1, 2, 0)                                                     # (P,V,5) view
+    loss = bivariate_loss(vp, torch.from_numpy(g["vtrgt"]).to(dev))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-6
+    grad = vp_store.grad.permute(1, 2, 0).cpu().numpy()
+    assert _maxdiff(grad, g["dvpred"]) < 2e-6 * max(1.0, np.abs(g["dvpred"]).max())
+    assert np.all(grad[0, 0] == 0)
+
+
+def test_bivariate_loss_batched(dev):
+    from social_stgcnn_amd.metrics import bivariate_loss
+    O = _oracle()
+    g = torch.Generator().manual_seed(5)
+    n, p, v = 4, 12, 9
+    peds = [9, 4, 1, 7]
+    vp = torch.randn(n, p, v, 5, generator=g) * 0.5
+    vt = torch.randn(n, p, v, 2, generator=g)
+    vpr = vp.clone().requires_grad_(True)
+    ref = torch.stack([O.bivariate_loss(vpr[i, :, :k], vt[i, :, :k]) for i, k in enumerate(peds)])
+    wts = torch.tensor([0.3, 1.0, 2.0, -0.5])
+    (ref * wts).sum().backward()
+    vpd = vp.to(dev).requires_grad_(True)
+    out = bivariate_loss(vpd, vt.to(dev), peds)
+    (out * wts.to(dev)).sum().backward()
+    assert _maxdiff(out.detach().cpu().numpy(), ref.detach().numpy()) < 2e-6
+    assert _maxdiff(vpd.grad.cpu().numpy(), vpr.grad.numpy()) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("v", VS)
+def test_eval_forward_golden(dev, v):
+    """R3-R5 with the shipped eth checkpoint: module outputs vs the reference's (fixture).
+    Bound: 2e-5 absolute on the bivariate parameters (north-star bar 1e-4)."""
+    from social_stgcnn_amd.model import social_stgcnn
+    w = _state(load_golden("weights_eth.npz"))
+    a = load_golden("adj_cases.npz")
+    f = load_golden("forward_eval.npz")
+    m = _model(dev, state=w).eval()
+    x = torch.from_numpy(a["nodes_%d" % v]).unsqueeze(0).permute(0, 3, 1, 2).to(dev)    # strided view
+    A = torch.from_numpy(a["lap_%d" % v]).to(dev)
+    with torch.no_grad():
+        y, a_out = m(x, A)
+        g, _ = m.st_gcns[0].gcn(x, A)
+        h, _ = m.st_gcns[0](x, A)
+        y2, _ = m(x, A)                 # parent re-packs after the child call
+    assert a_out is A
+    assert y.shape == (1, 5, 12, v) and y.is_contiguous()
+    assert _maxdiff(g.cpu().numpy(), f["gcn_%d" % v]) < 1e-5
+    assert _maxdiff(h.cpu().numpy(), f["stgcn_%d" % v]) < 1e-5
+    assert _maxdiff(y.cpu().numpy(), f["vpred_%d" % v]) < 2e-5
+    assert torch.equal(y, y2)
+
+
+def _train_case(dev, v, waves=None):
+    t = load_golden("train_fwd_bwd.npz")
+    a = load_golden("adj_cases.npz")
+    state = _state(t, "sd_%d/" % v)
+    m = _model(dev, state=state).train()
+    x = torch.from_numpy(a["nodes_%d" % v]).unsqueeze(0).permute(0, 3, 1, 2).to(dev)
+    A = torch.from_numpy(a["lap_%d" % v]).to(dev)
+    tgt = torch.from_numpy(a["prednodes_%d" % v]).to(dev)
+    return t, m, x, A, tgt
+
+
+@pytest.mark.parametrize("v", (3, 17, 57))
+def test_train_forward_backward_golden(dev, v):
+    """Reference train-mode forward + bivariate_loss + backward (fixture): V_pred, loss, every
+    parameter gradient (dead ones stay None), BatchNorm buffers after the step."""
+    from social_stgcnn_amd.metrics import bivariate_loss
+    t, m, x, A, tgt = _train_case(dev, v)
+    y, _ = m(x, A)
+    y.retain_grad()
+    v_pred = y.permute(0, 2, 3, 1).squeeze(0)
+    loss = bivariate_loss(v_pred, tgt)
+    loss.backward()
+    assert _maxdiff(y.detach().cpu().numpy(), t["vpred_%d" % v]) < 2e-5
+    assert abs(loss.item() - float(t["loss_%d" % v])) < 2e-5
+    assert _maxdiff(y.grad.cpu().numpy(), t["dvpred_%d" % v]) < 1e-6
+    worst = {}
+    for name, p in m.named_parameters():
+        ref = t["grad_%d/%s" % (v, name)]
+        if np.isnan(ref).all():
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, name
+        scale = max(1e-3, float(np.abs(ref).max()))
+        worst[name] = _maxdiff(p.grad.cpu().numpy(), ref) / scale
+    bad = {k: e for k, e in worst.items() if e > 2e-4}
+    assert not bad, "relative gradient errors: %s" % bad
+    for k, val in m.state_dict().items():
+        if "running" in k:
+            assert _maxdiff(val.cpu().numpy(), t["after_%d/%s" % (v, k)]) < 1e-6, k
+        if "num_batches" in k:
+            assert int(val) == int(t["after_%d/%s" % (v, k)]), k
+
+
+def test_batched_ragged_train_step_vs_oracle(dev):
+    """A padded ragged batch (num_peds) in one launch == the oracle's per-scene N=1 loop:
+    per-scene V_pred and losses, summed parameter gradients, sequentially folded BN buffers."""
+    from social_stgcnn_amd.metrics import bivariate_loss
+    O = _oracle()
+    a = load_golden("adj_cases.npz")
+    vs = [5, 17, 2, 32, 8, 3, 57, 17]
+    vmax = 57
+    m = _model(dev, seed=21).train()
+    state = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    keys = [k for k, _ in m.named_parameters()]
+    n = len(vs)
+    x = torch.zeros(n, 2, 8, vmax)
+    A = torch.zeros(n, 8, vmax, vmax)
+    tgt = torch.zeros(n, 12, vmax, 2)
+    for i, v in enumerate(vs):
+        x[i, :, :, :v] = torch.from_numpy(a["nodes_%d" % v]).permute(2, 0, 1)
+        A[i, :, :v, :v] = torch.from_numpy(a["lap_%d" % v])
+        tgt[i, :, :v] = torch.from_numpy(a["prednodes_%d" % v])
+    wts = torch.linspace(0.5, 1.5, n)
+    # oracle: sequential scenes
+    params = {k: state[k].clone().requires_grad_(True) for k in keys}
+    work = dict(state)
+    work.update(params)
+    ref_losses, ref_pred = [], []
+    for i, v in enumerate(vs):
+        l, vp = O.scene_loss(work, x[i:i + 1, :, :, :v], A[i, :, :v, :v], tgt[i, :, :v], True)
+        ref_losses.append(l)
+        ref_pred.append(vp.detach())
+    (torch.stack(ref_losses) * wts).sum().backward()
+    # HIP: one batch
+    y, _ = m(x.to(dev), A.to(dev), num_peds=vs)
+    losses = bivariate_loss(y.permute(0, 2, 3, 1), tgt.to(dev), vs)
+    (losses * wts.to(dev)).sum().backward()
+    yc = y.detach().cpu()
+    for i, v in enumerate(vs):
+        assert _maxdiff(yc[i, :, :, :v].permute(1, 2, 0).numpy(), ref_pred[i].numpy()) < 2e-5, i
+        assert torch.all(yc[i, :, :, v:] == 0)
+    assert _maxdiff(losses.detach().cpu().numpy(), torch.stack(ref_losses).detach().numpy()) < 2e-5
+    bad = {}
+    for name, p in m.named_parameters():
+        g = params[name].grad
+        if g is None:
+            assert p.grad is None, name
+            continue
+        scale = max(1e-3, float(g.abs().max()))
+        e = _maxdiff(p.grad.cpu().numpy(), g.numpy()) / scale
+        if e > 2e-4:
+            bad[name] = e
+    assert not bad, "relative gradient errors: %s" % bad
+    for k, val in m.state_dict().items():
+        if "running" in k:
+            assert _maxdiff(val.cpu().numpy(), work[k].numpy()) < 2e-6, k
+        if "num_batches" in k:
+            assert int(val) == int(work[k]), k
+
+
+@pytest.mark.parametrize("waves", (1, 2, 4, 8))
+def test_wave_count_variants_agree(dev, waves, monkeypatch):
+    """Every WAVES instantiation of the fused kernels computes the same scene."""
+    from social_stgcnn_amd.metrics import bivariate_loss
+    monkeypatch.setenv("STG_FWD_WAVES", str(waves))
+    monkeypatch.setenv("STG_BWD_WAVES", str(waves))
+    t, m, x, A, tgt = _train_case(dev, 17)
+    y, _ = m(x, A)
+    loss = bivariate_loss(y.permute(0, 2, 3, 1).squeeze(0), tgt)
+    loss.backward()
+    assert _maxdiff(y.detach().cpu().numpy(), t["vpred_17"]) < 2e-5
+    for name, p in m.named_parameters():
+        ref = t["grad_17/%s" % name]
+        if np.isnan(ref).all():
+            continue
+        scale = max(1e-3, float(np.abs(ref).max()))
+        assert _maxdiff(p.grad.cpu().numpy(), ref) / scale < 2e-4, name
+
+
+def test_stacked_blocks_and_input_grad(dev):
+    """n_stgcnn=2 (identity residual, dx through the first block) and n_txpcnn=2/1 variants,
+    including the gradient w.r.t. the input x, against oracle autograd."""
+    O = _oracle()
+    a = load_golden("adj_cases.npz")
+    for n_st, n_tx, v in ((2, 5, 8), (1, 2, 5), (1, 1, 17), (3, 3, 3)):
+        m = _model(dev, seed=n_st * 10 + n_tx, n_stgcnn=n_st, n_txpcnn=n_tx).train()
+        state = {k: val.detach().cpu().clone() for k, val in m.state_dict().items()}
+        keys = [k for k, _ in m.named_parameters()]
+        x = torch.from_numpy(a["nodes_%d" % v]).unsqueeze(0).permute(0, 3, 1, 2).contiguous()
+        A = torch.from_numpy(a["lap_%d" % v])
+        params = {k: state[k].clone().requires_grad_(True) for k in keys}
+        work = dict(state)
+        work.update(params)
+        xr = x.clone().requires_grad_(True)
+        ref = O.social_stgcnn_forward(work, xr, A, True, n_stgcnn=n_st, n_txpcnn=n_tx)
+        g = torch.Generator().manual_seed(3)
+        gy = torch.randn(ref.shape, generator=g)
+        (ref * gy).sum().backward()
+        xd = x.to(dev).requires_grad_(True)
+        y, _ = m(xd, A.to(dev))
+        (y * gy.to(dev)).sum().backward()
+        assert _maxdiff(y.detach().cpu().numpy(), ref.detach().numpy()) < 2e-5, (n_st, n_tx)
+        gs = max(1e-3, float(xr.grad.abs().max()))
+        assert _maxdiff(xd.grad.cpu().numpy(), xr.grad.numpy()) / gs < 2e-4, (n_st, n_tx)
+        for name, p in m.named_parameters():
+            gr = params[name].grad
+            if gr is None:
+                assert p.grad is None, name
+                continue
+            scale = max(1e-3, float(gr.abs().max()))
+            assert _maxdiff(p.grad.cpu().numpy(), gr.numpy()) / scale < 2e-4, (n_st, n_tx, name)
+
+
+def test_errors_are_loud(dev):
+    from social_stgcnn_amd import _lib, ops
+    from social_stgcnn_amd.model import social_stgcnn, st_gcn
+    with pytest.raises(RuntimeError):
+        ops.spatial_agg(torch.zeros(1, 2, 8, 4), torch.zeros(8, 4, 4))          # CPU tensor: no fallback
+    m = social_stgcnn(n_stgcnn=1, n_txpcnn=5, seq_len=8, pred_seq_len=12).to(dev)
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, 2, 8, 4, device=dev), torch.zeros(7, 4, 4, device=dev))   # model.py:65 assert
+    with pytest.raises(RuntimeError):
+        social_stgcnn(n_stgcnn=1, n_txpcnn=5, seq_len=6, pred_seq_len=12).to(dev)(
+            torch.zeros(1, 2, 6, 4, device=dev), torch.zeros(6, 4, 4, device=dev))   # unsupported seq_len
+    with pytest.raises(AssertionError):
+        st_gcn(2, 5, (2, 8))                                                       # model.py:105 assert
+    assert _lib.lib().stg_adj_build(None, 0, 0, 0, 0, None, 1, 4, 8, 1, None, None, None) == -1
+    assert b"null" in _lib.lib().stg_last_error()
+
+
+def test_full_size_properties(dev):
+    """BASELINE sizes (N=2048, V=32): size-independent properties instead of a CPU oracle run:
+    scene permutation equivariance, determinism, gradient additivity over batch halves."""
+    from social_stgcnn_amd import ops
+    from social_stgcnn_amd.metrics import bivariate_loss
+    rng = np.random.default_rng(1)
+    n, v = 2048, 32
+    rel = torch.from_numpy(rng.uniform(-0.5, 0.5, (n, v, 2, 8)).round(4).astype(np.float32)).to(dev)
+    rel[:, :, :, 0] = 0
+    nodes, A = ops.adj_build(rel)
+    x = nodes.permute(0, 3, 1, 2)
+    tgt = torch.from_numpy(rng.uniform(-0.5, 0.5, (n, 12, v, 2)).astype(np.float32)).to(dev)
+    m = _model(dev, seed=0).train()
+
+    def step(idx):
+        m.zero_grad(set_to_none=True)
+        y, _ = m(x[idx], A[idx])
+        l = bivariate_loss(y.permute(0, 2, 3, 1), tgt[idx])
+        l.sum().backward()
+        return y.detach(), l.detach(), torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
+
+    all_idx = torch.arange(n, device=dev)
+    y0, l0, g0 = step(all_idx)
+    y1, l1, g1 = step(all_idx)
+    assert torch.equal(y0, y1) and torch.equal(l0, l1) and torch.equal(g0, g1)      # deterministic
+    perm = torch.from_numpy(rng.permutation(n)).to(dev)
+    yp, lp, gp = step(perm)
+    assert torch.equal(yp, y0[perm]) and torch.equal(lp, l0[perm])                   # equivariance
+    assert float((gp - g0).abs().max()) < 1e-4 * float(g0.abs().max())               # order-only noise
+    _, _, ga = step(all_idx[: n // 2])
+    _, _, gb = step(all_idx[n // 2:])
+    assert float((ga + gb - g0).abs().max()) < 1e-4 * float(g0.abs().max())          # additivity
+    assert torch.isfinite(y0).all() and torch.isfinite(g0).all()
+    # symmetric Laplacian, zero first frame, rows of D^-1/2 (D-A) D^-1/2 in [-1, 1]
+    assert torch.equal(A, A.transpose(2, 3)) and torch.all(A[:, 0] == 0) and float(A.abs().max()) <= 1.0
