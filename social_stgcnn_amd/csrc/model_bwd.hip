@@ -3,7 +3,8 @@
 //
 // A workgroup walks scenes n = blockIdx.x, +gridDim.x, ...; its parameter-gradient accumulator
 // (all 7,563 floats) lives in LDS for the whole launch and leaves once as a slab; a second tiny
-// kernel sums the slabs (deterministic for a fixed grid; no global float atomics).
+// kernel sums the slabs (no global float atomics; the TXP weight-gradient tiles of the waves of a
+// workgroup meet in LDS through ds_add_f32, so the last bits depend on arrival order).
 //
 // Per scene, from the activations the forward saved (a_l, z_l of the TXP-CNN; ax, colsum, g, h2 and
 // the BatchNorm statistics of each st_gcn block):
@@ -198,8 +199,9 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
     const float *P_ = a.params;
     const bool train = a.lay.bn_mode == 1;
     const float inv_cnt = 1.0f / (float)cnt;
-    const float *w_ax = wsn + (int64_t)b.ws_ax * V, *w_cs = wsn + (int64_t)b.ws_cs * V;
-    const float *w_g = wsn + (int64_t)b.ws_g * V, *w_h2 = wsn + (int64_t)b.ws_h2 * V;
+    const float *wsa = wsn + a.lay.ws_hdr_floats;     // saved arrays sit behind the header
+    const float *w_ax = wsa + (int64_t)b.ws_ax * V, *w_cs = wsa + (int64_t)b.ws_cs * V;
+    const float *w_g = wsa + (int64_t)b.ws_g * V, *w_h2 = wsa + (int64_t)b.ws_h2 * V;
     const float *hdr = wsn + b.ws_hdr;
     float m1[C], r1[C], m2[C], r2[C], mr[C], rr[C];
 #pragma unroll
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
                 const bool is_out = l == L.L;
                 const int cin_l = l == 0 ? T : P;
                 // stage a_l (zero-bordered) and dz_l
-                const float *al = wsn + (int64_t)L.ws_a[l] * V;
+                const float *al = wsn + L.ws_hdr_floats + (int64_t)L.ws_a[l] * V;
                 for (int e = tid; e < cin_l * npos; e += NT) {
                     const int ch = e / npos, p = e - ch * npos;
                     ain[ch * SC + pt[p]] = al[e];
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
                     }
                     __syncthreads();
                 } else {
-                    const float *zl = wsn + (int64_t)L.ws_z[l] * V;
+                    const float *zl = wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V;
                     const float alpha = Pm[L.prelus + l];
                     float s[1] = {0.f};
                     for (int e = tid; e < P * npos; e += NT) {
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
         // ---- st_gcn blocks, last to first ------------------------------------------------------
         float *H1 = ain, *DH2 = ain + C * (T + 2) * V, *DB1 = DH2 + C * (T + 2) * V;
         for (int j = L.n_blocks - 1; j >= 0; --j) {
-            const float *xin = j > 0 ? wsn + (int64_t)L.blk[j - 1].ws_s * V : nullptr;
+            const float *xin = j > 0 ? wsn + L.ws_hdr_floats + (int64_t)L.blk[j - 1].ws_s * V : nullptr;
             float *dxs = j > 0 ? dcur : nullptr;
             float *dxg = j == 0 ? dxn : nullptr;
             if (L.blk[j].cin == Cfg::CIN0)

@@ -67,6 +67,7 @@ __device__ void stgcn_block_fwd(const FwdArgs &a, const BlockLayout &b, int n, i
     const bool train = a.lay.bn_mode == 1;
     const float eps = a.lay.eps;
     const float *an = a.adj + n * a.a_sn;
+    float *wsa = wsn ? wsn + a.lay.ws_hdr_floats : nullptr;    // saved arrays sit behind the header
 
     // ---- P1: aggregation of the CIN input channels + 1x1 conv (model.py:66-67) ------------------
     float s1[C];
@@ -89,9 +90,9 @@ __device__ void stgcn_block_fwd(const FwdArgs &a, const BlockLayout &b, int n, i
         }
         cs[q] = csum;
         if (wsn) {
-            wsn[(int64_t)b.ws_cs * V + q] = csum;
+            wsa[(int64_t)b.ws_cs * V + q] = csum;
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) wsn[(int64_t)b.ws_ax * V + (ci * T + t) * vi + w] = ax[ci];
+            for (int ci = 0; ci < CIN; ++ci) wsa[(int64_t)b.ws_ax * V + (ci * T + t) * vi + w] = ax[ci];
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -99,7 +100,7 @@ __device__ void stgcn_block_fwd(const FwdArgs &a, const BlockLayout &b, int n, i
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) g = fmaf(P_[b.gcn_w + c * CIN + ci], ax[ci], g);
             G[(c * T + t) * vi + w] = g;
-            if (wsn) wsn[(int64_t)b.ws_g * V + (c * T + t) * vi + w] = g;
+            if (wsn) wsa[(int64_t)b.ws_g * V + (c * T + t) * vi + w] = g;
             s1[c] += g;
         }
     }
@@ -180,7 +181,7 @@ __device__ void stgcn_block_fwd(const FwdArgs &a, const BlockLayout &b, int n, i
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             H[(c * T + t) * vi + w] = h[c];
-            if (wsn) wsn[(int64_t)b.ws_h2 * V + (c * T + t) * vi + w] = h[c];
+            if (wsn) wsa[(int64_t)b.ws_h2 * V + (c * T + t) * vi + w] = h[c];
             s2r[c] += h[c];
         }
         if (b.residual == 2) {
@@ -282,7 +283,7 @@ __device__ void stgcn_block_fwd(const FwdArgs &a, const BlockLayout &b, int n, i
                 }
                 const float s = (a.lay.use_mdn || u > 0.f) ? u : ao * u;
                 H[i] = s;
-                if (wsn) wsn[(int64_t)b.ws_s * V + i] = s;
+                if (wsn) wsa[(int64_t)b.ws_s * V + i] = s;
                 if (to_txp) {
                     // v.view(N, T, C, V) (model.py:187): flat plane index f = c*T+t -> (f / C, f % C)
                     const int f = c * T + t, ch = f / C, row = f - ch * C;
@@ -439,8 +440,8 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a) 
         const float *Pm = a.params;
         float *in = bufA, *out = bufB;
         for (int l = 0; l < L.L; ++l) {
-            float *zs = wsn ? wsn + (int64_t)L.ws_z[l] * V : nullptr;
-            float *as = wsn ? wsn + (int64_t)L.ws_a[l + 1] * V : nullptr;
+            float *zs = wsn ? wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V : nullptr;
+            float *as = wsn ? wsn + L.ws_hdr_floats + (int64_t)L.ws_a[l + 1] * V : nullptr;
             const float alpha = Pm[L.prelus + l];
             if (l == 0)
                 txp_layer_fwd<Cfg::T, WAVES>(Pm + L.txp_w[0], Pm + L.txp_b[0], alpha, 0, in, out, vi, V, zs, as,

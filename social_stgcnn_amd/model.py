@@ -127,7 +127,7 @@ class st_gcn(nn.Module):
         flat_b = self._pb.ensure(bufs)
         desc = ops.make_desc(1, 0, self.in_channels, self.out_channels, x.shape[2], 0, self.kt, self.residual_kind,
                              self.use_mdn, self.training, self.tcn[0].eps, self.tcn[0].momentum)
-        y = ops.fused_model(x, A, num_peds, desc, flat_p, flat_b, nbt, frozenset(), params)
+        y = ops.fused_model(x, A, num_peds, desc, flat_p, flat_b, nbt, frozenset(), params, self)
         return y, A
 
 
@@ -204,5 +204,5 @@ class social_stgcnn(nn.Module):
         desc = ops.make_desc(self.n_stgcnn, self.n_txpcnn, self.input_feat, self.output_feat, self.seq_len,
                              self.pred_seq_len, self.kt, self.st_gcns[0].residual_kind, False, self.training,
                              bn.eps, bn.momentum)
-        y = ops.fused_model(v, a, num_peds, desc, flat_p, flat_b, nbt, dead, params)
+        y = ops.fused_model(v, a, num_peds, desc, flat_p, flat_b, nbt, dead, params, self)
         return y, a

@@ -173,11 +173,31 @@ def make_desc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, use
                      1 if training else 0, eps, momentum)
 
 
+class KernelTimer:
+    """HIP-event pairs around the fused forward / backward launches on the stream the kernels run on
+    (torch's current stream).  Enabled by bench.py for the roofline leg; off by default."""
+
+    def __init__(self):
+        self.events = {"model_fwd": [], "model_bwd": []}
+
+    def bracket(self, name):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.events[name].append((a, b))
+        return a, b
+
+    def mean_ms(self, name):
+        ev = self.events[name]
+        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
+
+
+TIMER = None
+
+
 class _FusedModel(torch.autograd.Function):
     """x (N,Cin,T,V), adj -> y.  Extra (non-differentiable) arguments carry the packed buffers."""
 
     @staticmethod
-    def forward(ctx, x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, *params):
+    def forward(ctx, x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, holder, *params):
         require_gpu(x, adj, flat_params, flat_buffers)
         _lib.as_f32(x, "x")
         _lib.as_f32(adj, "adj")
@@ -203,9 +223,14 @@ class _FusedModel(torch.autograd.Function):
             sf = L.stg_model_stat_floats(ctypes.byref(desc))
             stats = torch.empty((n, max(int(sf), 1)), device=x.device, dtype=torch.float32)
         sn, sc, st, sv = x.stride()
+        ev = TIMER.bracket("model_fwd") if TIMER is not None else None
+        if ev:
+            ev[0].record()
         check(L.stg_model_fwd(ctypes.byref(desc), ptr(flat_params), ptr(flat_buffers), ptr(x), sn, sc, st, sv,
                               ptr(adj_c), a_sn, ptr(peds), n, v, ptr(y), ptr(ws), ptr(stats), stream_ptr()),
               "stg_model_fwd")
+        if ev:
+            ev[1].record()
         if training:
             arr = (ctypes.c_void_p * len(nbt))(*[b.data_ptr() for b in nbt])
             # nbt[k] counts forwards of BatchNorm k; buffers are interleaved (mean, var) per BatchNorm, the
@@ -215,6 +240,7 @@ class _FusedModel(torch.autograd.Function):
         ctx.desc = desc
         ctx.a_sn = a_sn
         ctx.dead = dead
+        ctx.holder = holder
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.flat_params = flat_params
         ctx.flat_buffers = flat_buffers
@@ -238,9 +264,14 @@ class _FusedModel(torch.autograd.Function):
         grad = torch.empty(np_, device=x.device, dtype=torch.float32)
         dx = torch.empty((n, cin, t, v), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         sn, sc, st, sv = x.stride()
+        ev = TIMER.bracket("model_bwd") if TIMER is not None else None
+        if ev:
+            ev[0].record()
         check(L.stg_model_bwd(ctypes.byref(desc), ptr(ctx.flat_params), ptr(ctx.flat_buffers), ptr(x), sn, sc, st,
                               sv, ptr(adj_c), ctx.a_sn, ptr(peds), n, v, ptr(dy), ptr(ws), ptr(slabs), ptr(grad),
                               ptr(dx), stream_ptr()), "stg_model_bwd")
+        if ev:
+            ev[1].record()
         grads = []
         off = 0
         for i, shp in enumerate(ctx.shapes):
@@ -249,12 +280,13 @@ class _FusedModel(torch.autograd.Function):
                 cnt *= s
             grads.append(None if i in ctx.dead else grad[off:off + cnt].view(shp))
             off += cnt
-        ctx.flat_grad = grad
-        return (dx, None, None, None, None, None, None, None, *grads)
+        if ctx.holder is not None:
+            ctx.holder._flat_grad = grad       # the trainer all-reduces / applies this buffer directly
+        return (dx, None, None, None, None, None, None, None, None, *grads)
 
 
-def fused_model(x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, params):
-    return _FusedModel.apply(x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, *params)
+def fused_model(x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, params, holder=None):
+    return _FusedModel.apply(x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, holder, *params)
 
 
 # --------------------------------------------------------------------------------------------
