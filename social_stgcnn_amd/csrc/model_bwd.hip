@@ -32,6 +32,7 @@ struct BwdArgs {
     const float *dy, *ws;
     int64_t ws_stride;
     float *slabs, *dx;
+    int debug_skip;   // timing-only diagnostic (STG_DEBUG_SKIP): 1 wgrad, 2 dgrad, 4 st_gcn -- wrong results
 };
 
 constexpr int kRedMax = 96;   // widest block reduction (values)
@@ -569,11 +570,11 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
                 const int w_off = is_out ? L.out_w : L.txp_w[l];
                 const int b_off = is_out ? L.out_b : L.txp_b[l];
                 if (l == 0) {
-                    txp_wgrad<Cfg::T, WAVES>(dzb, ain, pt, gsm, w_off, b_off, vi);
-                    txp_dgrad<Cfg::T, WAVES>(Pm + w_off, dzb, dcur, vi, false);
+                    if (!(a.debug_skip & 1)) txp_wgrad<Cfg::T, WAVES>(dzb, ain, pt, gsm, w_off, b_off, vi);
+                    if (!(a.debug_skip & 2)) txp_dgrad<Cfg::T, WAVES>(Pm + w_off, dzb, dcur, vi, false);
                 } else {
-                    txp_wgrad<Cfg::P, WAVES>(dzb, ain, pt, gsm, w_off, b_off, vi);
-                    txp_dgrad<Cfg::P, WAVES>(Pm + w_off, dzb, dcur, vi, !is_out);
+                    if (!(a.debug_skip & 1)) txp_wgrad<Cfg::P, WAVES>(dzb, ain, pt, gsm, w_off, b_off, vi);
+                    if (!(a.debug_skip & 2)) txp_dgrad<Cfg::P, WAVES>(Pm + w_off, dzb, dcur, vi, !is_out);
                 }
                 __syncthreads();
             }
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
         }
         // ---- st_gcn blocks, last to first ------------------------------------------------------
         float *H1 = ain, *DH2 = ain + C * (T + 2) * V, *DB1 = DH2 + C * (T + 2) * V;
-        for (int j = L.n_blocks - 1; j >= 0; --j) {
+        for (int j = L.n_blocks - 1; j >= 0 && !(a.debug_skip & 4); --j) {
             const float *xin = j > 0 ? wsn + L.ws_hdr_floats + (int64_t)L.blk[j - 1].ws_s * V : nullptr;
             float *dxs = j > 0 ? dcur : nullptr;
             float *dxg = j == 0 ? dxn : nullptr;
@@ -603,13 +604,24 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
     for (int e = tid; e < L.n_params; e += NT) slab[e] = gsm[e];
 }
 
-__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int n_slabs, int n_params,
-                                    float *__restrict__ grad) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_params) return;
+// grad[p] = sum over slabs.  One workgroup owns 32 consecutive parameters (one 128-byte line per slab
+// row); its 8 lane-groups stride over the slabs, partial sums meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int n_slabs, int n_params,
+                                                           float *__restrict__ grad) {
+    __shared__ float part[8][32];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int p = blockIdx.x * 32 + col;
     float s = 0.f;
-    for (int k = 0; k < n_slabs; ++k) s += slabs[(int64_t)k * n_params + p];
-    grad[p] = s;
+    if (p < n_params)
+        for (int k = grp; k < n_slabs; k += 8) s += slabs[(int64_t)k * n_params + p];
+    part[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && p < n_params) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += part[g][col];
+        grad[p] = t;
+    }
 }
 
 static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves) {
@@ -681,6 +693,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     a.x_sn = x_sn; a.x_sc = x_sc; a.x_st = x_st; a.x_sv = x_sv;
     a.adj = adj; a.a_sn = a_sn; a.num_peds = num_peds; a.N = N; a.V = V;
     a.dy = dy; a.ws = ws; a.ws_stride = ws_floats_per_scene(a.lay, V); a.slabs = slabs; a.dx = dx;
+    if (const char *e = getenv("STG_DEBUG_SKIP")) a.debug_skip = atoi(e);
     const int waves = bwd_waves(V);
     const size_t lds = bwd_lds_bytes(a.lay, V, waves);
     STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_bwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
@@ -702,7 +715,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
 #undef STG_LAUNCH_BWD
     STG_LAUNCH_CHECK("stg_model_bwd");
     const int np = a.lay.n_params;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((np + 255) / 256), dim3(256), 0, st, slabs, grid, np, grad_params);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((np + 31) / 32), dim3(256), 0, st, slabs, grid, np, grad_params);
     STG_LAUNCH_CHECK("stg_model_bwd: reduce_slabs");
     return STG_OK;
 }

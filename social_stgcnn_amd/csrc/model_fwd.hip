@@ -27,6 +27,7 @@ struct FwdArgs {
     float *y, *ws;
     int64_t ws_stride;
     float *stats;
+    int debug_skip;   // timing-only diagnostic (STG_DEBUG_SKIP): 16 TXP-CNN, 32 st_gcn -- wrong results
 };
 
 template <int K, int WAVES>
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a) 
                 for (int e = tid; e < P * SC; e += NT) bufA[e] = 0.f;
         }
         __syncthreads();
-        for (int j = 0; j < L.n_blocks; ++j) {
+        for (int j = 0; j < L.n_blocks && !(a.debug_skip & 32); ++j) {
             const bool last = j == L.n_blocks - 1;
             float *yb = (last && L.n_txp == 0) ? yn : nullptr;
             if (L.blk[j].cin == Cfg::CIN0)
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a) 
                                                last && L.n_txp > 0, bufA, yb);
             float *tmp = X; X = H; H = tmp;      // block output becomes the next block's input
         }
-        if (L.n_txp == 0) continue;
+        if (L.n_txp == 0 || (a.debug_skip & 16)) continue;
         // ---- TXP-CNN (model.py:187-195) ------------------------------------------------------
         float *bufB = reg;
         for (int e = tid; e < P * SC; e += NT) bufB[e] = 0.f;
@@ -480,6 +481,7 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     a.x_sn = x_sn; a.x_sc = x_sc; a.x_st = x_st; a.x_sv = x_sv;
     a.adj = adj; a.a_sn = a_sn; a.num_peds = num_peds; a.N = N; a.V = V;
     a.y = y; a.ws = ws; a.ws_stride = ws_floats_per_scene(a.lay, V); a.stats = stats;
+    if (const char *e = getenv("STG_DEBUG_SKIP")) a.debug_skip = atoi(e);
     int waves = V <= 12 ? 1 : (V <= 40 ? 2 : (V <= 80 ? 4 : 8));
     if (const char *e = getenv("STG_FWD_WAVES")) {
         const int w = atoi(e);

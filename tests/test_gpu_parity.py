@@ -68,7 +68,9 @@ def _grad_errors(named_got, ref_of):
             sib = refs.get(name[:-4] + "weight")
             if sib is not None:
                 scale = max(scale, float(np.abs(sib).max()))
-        out[name] = _maxdiff(got.cpu().numpy(), ref) / scale
+        err = _maxdiff(got.cpu().numpy(), ref) / scale
+        # pure-noise entries get a 10x looser bar (they scale with depth / batch, not with the kernels)
+        out[name] = err / 10.0 if name.endswith(_ZERO_GRAD_BIASES) else err
     return out
 
 
