@@ -116,8 +116,9 @@ int64_t stg_model_ws_floats(const stg_model_desc *d, int V);
 /* Per-scene batch statistics the forward emits in bn_mode 1: (N, stat_floats) =
  * per block, per BatchNorm: mean[C], unbiased var[C].                                           */
 int64_t stg_model_stat_floats(const stg_model_desc *d);
-/* Number of partial-gradient slabs (of stg_model_param_count floats each) stg_model_bwd needs. */
-int64_t stg_model_bwd_slabs(const stg_model_desc *d, int N, int V);
+/* Scratch floats stg_model_bwd needs (partial-gradient slab rows of its kernels + the dz hand-off
+ * between the input-gradient kernel and the weight-gradient kernel). */
+int64_t stg_model_bwd_scratch_floats(const stg_model_desc *d, int N, int V);
 
 /* x (N,c_in,t_obs,V) strided; adj (N,t_obs,V,V), batch stride a_sn (0 = shared);
  * y: (N,c_out,t_pred,V) when n_txpcnn>0, else the block output (N,c_out,t_obs,V).
@@ -127,11 +128,12 @@ int stg_model_fwd(const stg_model_desc *d, const float *params, const float *buf
                   const float *adj, int64_t a_sn, const int32_t *num_peds, int N, int V,
                   float *y, float *ws, float *stats, void *stream);
 /* dy like y.  grad_params (param_count) is OVERWRITTEN with the gradient summed over the batch;
- * dx (N,c_in,t_obs,V) may be NULL.  slabs: stg_model_bwd_slabs * param_count floats scratch.    */
+ * dx (N,c_in,t_obs,V) may be NULL.  scratch: stg_model_bwd_scratch_floats floats, 16-byte aligned
+ * (ws must be 16-byte aligned too).                                                               */
 int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buffers,
                   const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv,
                   const float *adj, int64_t a_sn, const int32_t *num_peds, int N, int V,
-                  const float *dy, const float *ws, float *slabs, float *grad_params, float *dx,
+                  const float *dy, const float *ws, float *scratch, float *grad_params, float *dx,
                   void *stream);
 /* Sequential-fold update of the BatchNorm running statistics with the per-scene statistics of a
  * batch, exactly as N successive reference forwards would (momentum update per scene,

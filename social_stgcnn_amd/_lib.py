@@ -41,7 +41,7 @@ _SIGNATURES = {
     "stg_model_buffer_count": (c_l, [ctypes.POINTER(ModelDesc)]),
     "stg_model_ws_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i]),
     "stg_model_stat_floats": (c_l, [ctypes.POINTER(ModelDesc)]),
-    "stg_model_bwd_slabs": (c_l, [ctypes.POINTER(ModelDesc), c_i, c_i]),
+    "stg_model_bwd_scratch_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i, c_i]),
     "stg_model_fwd": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_f, c_l, c_l, c_l, c_l, c_f, c_l, c_f, c_i, c_i,
                             c_f, c_f, c_f, c_f]),
     "stg_model_bwd": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_f, c_l, c_l, c_l, c_l, c_f, c_l, c_f, c_i, c_i,

@@ -5,6 +5,9 @@
 // degree d_h = 1 + sum_{k!=h} a_hk (fp64 accumulation of fp32 weights, one lane per (t,h) row),
 // pass 2 streams the T V x V tiles to HBM with coalesced 16-byte stores:
 //   L_hh = (d_h - 1)/d_h,   L_hk = -a_hk / sqrt(d_h d_k),   a_hk = 1/||p_h - p_k||  (0 if equal).
+// Diagonal and off-diagonal use ONE formula, w * (dinv_h * dinv_k) with w = d_h-1 resp. -a_hk, so that the
+// exact cancellations of the reference's fp64 result (two-pedestrian scenes: L = c [[1,-1],[-1,1]], which
+// makes the st_gcn BatchNorm mean exactly 0 and puts PReLU inputs exactly on the kink) survive in fp32.
 // Algorithmic bytes per scene-window: 64*V read + 32*V*V (+64*V nodes) written.
 #include "common.hpp"
 
@@ -29,7 +32,7 @@ __global__ __launch_bounds__(256) void adj_build_kernel(
     float *px = sm;                // [T][V]
     float *py = px + T * V;        // [T][V]
     float *dinv = py + T * V;      // [T][V]  1/sqrt(d)
-    float *diag = dinv + T * V;    // [T][V]  (d-1)/d
+    float *diag = dinv + T * V;    // [T][V]  d-1 (sum of the off-diagonal weights)
     const int n = blockIdx.x, tid = threadIdx.x;
     int vi = num_peds ? num_peds[n] : V;
     vi = vi < 0 ? 0 : (vi > V ? V : vi);
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(256) void adj_build_kernel(
                 for (int k = 0; k < vi; ++k)
                     if (k != h) acc += (double)inv_dist(hx, hy, qx[k], qy[k]);
                 dinv[e] = (float)(1.0 / sqrt(acc));
-                diag[e] = (float)((acc - 1.0) / acc);
+                diag[e] = (float)(acc - 1.0);
             }
         }
         __syncthreads();
@@ -80,8 +83,8 @@ __global__ __launch_bounds__(256) void adj_build_kernel(
                     float v = 0.f;
                     if (k < vi) {
                         if (k == h)
-                            v = normalize ? diag[th] : 1.f;
-                        else {
+                            v = normalize ? diag[th] * (dh * dh) : 1.f;     // same formula as off-diagonal:
+                        else {                                              // V=2 rows cancel exactly like the reference's
                             const float a = inv_dist(hx, hy, qx[k], qy[k]);
                             v = normalize ? -(a * (dh * qd[k])) : a;   // dh*dk commutes: L is bitwise symmetric
                         }
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void adj_build_kernel(
             float v = 0.f;
             if (h < vi && k < vi) {
                 if (k == h)
-                    v = normalize ? diag[th] : 1.f;
+                    v = normalize ? diag[th] * (dinv[th] * dinv[th]) : 1.f;
                 else {
                     const float a = inv_dist(px[th], py[th], px[t * V + k], py[t * V + k]);
                     v = normalize ? -(a * (dinv[th] * dinv[t * V + k])) : a;

@@ -1,22 +1,23 @@
-// model_bwd: backward of social_stgcnn.forward (model.py:182-198) / st_gcn.forward (model.py:145-155)
-// as ONE scene-resident kernel with persistent workgroups.
+// model_bwd: backward of social_stgcnn.forward (model.py:182-198) / st_gcn.forward (model.py:145-155).
 //
-// A workgroup walks scenes n = blockIdx.x, +gridDim.x, ...; its parameter-gradient accumulator
-// (all 7,563 floats) lives in LDS for the whole launch and leaves once as a slab; a second tiny
-// kernel sums the slabs (no global float atomics; the TXP weight-gradient tiles of the waves of a
-// workgroup meet in LDS through ds_add_f32, so the last bits depend on arrival order).
+// Two kernels + a slab reduction, all fed by what the forward saved per scene (zero-bordered planes
+// a_0..a_L and pre-activations z_l of the TXP-CNN; ax, colsum, g, h2 and the BatchNorm statistics of
+// each st_gcn block):
 //
-// Per scene, from the activations the forward saved (a_l, z_l of the TXP-CNN; ax, colsum, g, h2 and
-// the BatchNorm statistics of each st_gcn block):
-//   TXP-CNN, output conv first then hidden layers in reverse:
-//     dz      = d(out) * prelu'(z)                       (VALU; also the PReLU slope gradient)
-//     dW, db += dz (x) im2col(a_l)                       MFMA 16x16x4 f32: M = 12 out-channels,
-//                                                        N = (tap, in-channel) columns + a ones column
-//                                                        (bias gradient), K = scene positions
-//     d(a_l)  = conv_transpose(dz, W) [+ d(out)]         MFMA, same implicit GEMM as the forward with
-//                                                        flipped taps and W^T
-//   st_gcn block: BatchNorm backward with PER-SCENE statistics, PReLU, temporal conv, 1x1 convs --
-//   VALU with wave-shuffle + LDS block reductions.
+//  K1 model_bwd_kernel<W>   scene-resident, persistent workgroups of W wave64.  Per scene, output conv
+//     first then the hidden TXP layers in reverse:
+//        dz_l   = d(a_{l+1}) * prelu'(z_l)        VALU (+ PReLU slope gradient); dz_l also goes to HBM for K2
+//        d(a_l) = conv_transpose(dz_l, W_l) [+ d(a_{l+1})]   MFMA 16x16x4 f32: the forward's implicit
+//                                                           GEMM with W^T and flipped taps
+//     then the st_gcn blocks: BatchNorm backward with PER-SCENE statistics, PReLU, temporal conv,
+//     1x1 convs -- VALU with wave-shuffle + LDS block reductions.  Small-parameter gradients
+//     (block parameters, PReLU slopes) accumulate in LDS for the whole launch and leave as one slab row.
+//  K2 txp_wgrad_kernel<W>   the TXP weight/bias gradients as ONE skinny GEMM per layer over ALL scenes:
+//        dW_l[co][ci][tap] = sum_{scene,pos} dz_l[co][pos] a_l[ci][pos+tap],  db_l = sum dz_l
+//     M = 12 out-channels (16-row tile), N = 9*c_in columns + a ones column (bias), K = every position of
+//     every scene.  Each wave owns scenes round-robin with a private LDS image (plane a_l + dz_l) and keeps
+//     the N/16 accumulator tiles in VGPRs for the whole launch -- no barriers, no atomics.
+//  reduce_slabs_kernel      sums the slab rows of K1 and K2 into the flat gradient in a fixed order.
 #include "model_common.hpp"
 
 namespace stg {
@@ -31,9 +32,30 @@ struct BwdArgs {
     int N, V;
     const float *dy, *ws;
     int64_t ws_stride;
-    float *slabs, *dx;
+    float *slab1;     // K1 slab rows: [gridDim.x][n_blk_params + n_txp]
+    float *dzg;       // dz_l of the hidden TXP layers for K2: [N][L][P*C*V]
+    float *dx;
     int debug_skip;   // timing-only diagnostic (STG_DEBUG_SKIP): 1 wgrad, 2 dgrad, 4 st_gcn -- wrong results
 };
+
+// K2 arguments
+struct WgradArgs {
+    ModelLayout lay;
+    const int32_t *num_peds;
+    int N, V;
+    const float *dy, *ws, *dzg;
+    int64_t ws_stride;
+    float *slab2;          // [layer 0..L][rows][row_len(layer)] packed, see wgrad_slab_base()
+    int rows;              // slab rows per layer = gridDim.x * WAVES
+};
+
+// slab geometry of K2: layer 0 has c_in = T, layers 1..L (L = output conv) have c_in = P
+__host__ __device__ inline int wgrad_row_len(int layer) {
+    return Cfg::P * (layer == 0 ? Cfg::T : Cfg::P) * 9 + Cfg::P;
+}
+__host__ __device__ inline int64_t wgrad_slab_base(int layer, int rows) {
+    return layer == 0 ? 0 : (int64_t)rows * (wgrad_row_len(0) + (int64_t)(layer - 1) * wgrad_row_len(1));
+}
 
 constexpr int kRedMax = 96;   // widest block reduction (values)
 
@@ -120,65 +142,6 @@ __device__ void txp_dgrad(const float *__restrict__ W, const float *dzb, float *
                 if (ci < CINL) {
                     const int i = (ci * C + hh[u]) * vi + ww[u];
                     dcur[i] = accumulate ? dcur[i] + acc[r] : acc[r];
-                }
-            }
-        }
-    }
-}
-
-// dW[co][ci][tap] += sum_pos dz[co][pos] a[ci][pos + tap], db[co] += sum_pos dz[co][pos]
-// (K = positions, split over the waves; partial tiles are added into the LDS accumulator gsm).
-template <int CINL, int WAVES>
-__device__ void txp_wgrad(const float *dzb, const float *ain, const int *pt, float *gsm, int w_off, int b_off,
-                          int vi) {
-    constexpr int C = Cfg::C, P = Cfg::P;
-    constexpr int NCOL = 9 * CINL + 1, NTILE = (NCOL + 15) / 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nq = lane & 15, kq = lane >> 4;
-    const int SW = txp_sw(vi), SC = txp_sc(vi);
-    const int npos = C * vi, nsteps = (npos + 3) >> 2;
-    const int co_a = nq < P ? nq : P - 1;     // rows 12..15 of the tile are never read back
-    int boff[NTILE];
-    bool bone[NTILE];
-#pragma unroll
-    for (int tl = 0; tl < NTILE; ++tl) {
-        int col = tl * 16 + nq;
-        bone[tl] = col == NCOL - 1;
-        if (col > NCOL - 2) col = NCOL - 2;
-        const int tap = col / CINL, ci = col - tap * CINL;
-        boff[tl] = ci * SC + (tap / 3 - 1) * SW + (tap % 3 - 1);
-    }
-    f32x4 acc[NTILE];
-#pragma unroll
-    for (int tl = 0; tl < NTILE; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s = wave; s < nsteps; s += WAVES) {
-        const int p = 4 * s + kq;
-        const bool ok = p < npos;
-        const int off = pt[ok ? p : 0];
-        const float av = ok ? dzb[co_a * SC + off] : 0.f;
-        const int offb = ok ? off : SW + 1;
-#pragma unroll
-        for (int tl = 0; tl < NTILE; ++tl) {
-            const float bv = bone[tl] ? 1.f : ain[boff[tl] + offb];
-            acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[tl], 0, 0, 0);
-        }
-    }
-    if (kq < 3) {
-#pragma unroll
-        for (int tl = 0; tl < NTILE; ++tl) {
-            const int col = tl * 16 + nq;
-            if (col < NCOL) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = 4 * kq + r;
-                    int idx;
-                    if (col == NCOL - 1) {
-                        idx = b_off + co;
-                    } else {
-                        const int tap = col / CINL, ci = col - tap * CINL;
-                        idx = w_off + (co * CINL + ci) * 9 + tap;
-                    }
-                    atomicAdd(&gsm[idx], acc[tl][r]);
                 }
             }
         }
@@ -497,17 +460,16 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
     const int plane_floats = P * scmax;
     // st_gcn phase needs 3 planes: h1 [C][T+2][V], dh2 [C][T+2][V], db1 [C][T][V]
     const int st_floats = (2 * C * (T + 2) + C * T) * V;
-    const int two_planes = 2 * plane_floats > st_floats ? 2 * plane_floats : st_floats;
-    float *gsm = sm;                                  // [n_params]
-    float *ain = gsm + ((L.n_params + 3) & ~3);       // [P][SC]   a_l, zero-bordered
-    float *dzb = ain + plane_floats;                  // [P][SC]   dz_l, zero-bordered
-    float *dcur = ain + two_planes;                   // [P*C*V]   gradient w.r.t. the layer output
+    const int reg_floats = plane_floats > st_floats ? plane_floats : st_floats;
+    const int n_small = L.n_blk_params + L.n_txp;
+    float *gsm = sm;                                  // [n_small] block parameters, then the PReLU slopes
+    float *dzb = gsm + ((n_small + 3) & ~3);          // [P][SC]   dz_l, zero-bordered (aliases the st_gcn planes)
+    float *dcur = dzb + reg_floats;                   // [P*C*V]   gradient w.r.t. the layer output
     float *red = dcur + P * C * V;                    // [WAVES*kRedMax]
     float *tot = red + WAVES * kRedMax;               // [kRedMax]
-    int *pt = reinterpret_cast<int *>(tot + kRedMax); // [C*V] position -> plane offset
     const float *Pm = a.params;
 
-    for (int e = tid; e < L.n_params; e += NT) gsm[e] = 0.f;
+    for (int e = tid; e < n_small; e += NT) gsm[e] = 0.f;
 
     for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
         int vi = a.num_peds ? a.num_peds[n] : V;
@@ -525,56 +487,42 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
         const float *dyn = a.dy + (int64_t)n * out_rows * V;
         __syncthreads();
         if (L.n_txp > 0) {
-            // ---- TXP-CNN backward ----------------------------------------------------------------
-            for (int e = tid; e < P * SC; e += NT) {
-                ain[e] = 0.f;
-                dzb[e] = 0.f;
-            }
-            for (int e = tid; e < npos; e += NT) {
-                const int h = e / vi, w = e - h * vi;
-                pt[e] = (h + 1) * SW + (w + 1);
-            }
+            // ---- TXP-CNN backward (input-gradient chain) -------------------------------------------
+            for (int e = tid; e < P * SC; e += NT) dzb[e] = 0.f;
             __syncthreads();
             for (int l = L.L; l >= 0; --l) {
                 const bool is_out = l == L.L;
-                const int cin_l = l == 0 ? T : P;
-                // stage a_l (zero-bordered) and dz_l
-                const float *al = wsn + L.ws_hdr_floats + (int64_t)L.ws_a[l] * V;
-                for (int e = tid; e < cin_l * npos; e += NT) {
-                    const int ch = e / npos, p = e - ch * npos;
-                    ain[ch * SC + pt[p]] = al[e];
-                }
                 if (is_out) {
                     for (int e = tid; e < P * npos; e += NT) {
                         const int ch = e / npos, p = e - ch * npos, h = p / vi, w = p - h * vi;
-                        dzb[ch * SC + pt[p]] = dyn[(int64_t)(ch * C + h) * V + w];
+                        dzb[ch * SC + (h + 1) * SW + (w + 1)] = dyn[(int64_t)(ch * C + h) * V + w];
                     }
                     __syncthreads();
                 } else {
                     const float *zl = wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V;
+                    float *dzo = a.dzg + ((int64_t)n * L.L + l) * (P * C * V);
                     const float alpha = Pm[L.prelus + l];
                     float s[1] = {0.f};
                     for (int e = tid; e < P * npos; e += NT) {
-                        const int ch = e / npos, p = e - ch * npos;
+                        const int ch = e / npos, p = e - ch * npos, h = p / vi, w = p - h * vi;
                         const float z = zl[e], d = dcur[e];
                         float dz = d;
                         if (!(z > 0.f)) {
                             dz = alpha * d;
                             s[0] = fmaf(d, z, s[0]);
                         }
-                        dzb[ch * SC + pt[p]] = dz;
+                        dzb[ch * SC + (h + 1) * SW + (w + 1)] = dz;
+                        dzo[e] = dz;
                     }
                     block_reduce<1, WAVES>(s, red, tot);
-                    if (tid == 0) gsm[L.prelus + l] += tot[0];
+                    if (tid == 0) gsm[L.n_blk_params + l] += tot[0];
                 }
                 const int w_off = is_out ? L.out_w : L.txp_w[l];
-                const int b_off = is_out ? L.out_b : L.txp_b[l];
-                if (l == 0) {
-                    if (!(a.debug_skip & 1)) txp_wgrad<Cfg::T, WAVES>(dzb, ain, pt, gsm, w_off, b_off, vi);
-                    if (!(a.debug_skip & 2)) txp_dgrad<Cfg::T, WAVES>(Pm + w_off, dzb, dcur, vi, false);
-                } else {
-                    if (!(a.debug_skip & 1)) txp_wgrad<Cfg::P, WAVES>(dzb, ain, pt, gsm, w_off, b_off, vi);
-                    if (!(a.debug_skip & 2)) txp_dgrad<Cfg::P, WAVES>(Pm + w_off, dzb, dcur, vi, !is_out);
+                if (!(a.debug_skip & 2)) {
+                    if (l == 0)
+                        txp_dgrad<Cfg::T, WAVES>(Pm + w_off, dzb, dcur, vi, false);
+                    else
+                        txp_dgrad<Cfg::P, WAVES>(Pm + w_off, dzb, dcur, vi, !is_out);
                 }
                 __syncthreads();
             }
@@ -586,7 +534,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
             __syncthreads();
         }
         // ---- st_gcn blocks, last to first ------------------------------------------------------
-        float *H1 = ain, *DH2 = ain + C * (T + 2) * V, *DB1 = DH2 + C * (T + 2) * V;
+        float *H1 = dzb, *DH2 = dzb + C * (T + 2) * V, *DB1 = DH2 + C * (T + 2) * V;
         for (int j = L.n_blocks - 1; j >= 0 && !(a.debug_skip & 4); --j) {
             const float *xin = j > 0 ? wsn + L.ws_hdr_floats + (int64_t)L.blk[j - 1].ws_s * V : nullptr;
             float *dxs = j > 0 ? dcur : nullptr;
@@ -600,54 +548,191 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
         }
     }
     __syncthreads();
-    float *slab = a.slabs + (int64_t)blockIdx.x * L.n_params;
-    for (int e = tid; e < L.n_params; e += NT) slab[e] = gsm[e];
+    float *slab = a.slab1 + (int64_t)blockIdx.x * n_small;
+    for (int e = tid; e < n_small; e += NT) slab[e] = gsm[e];
 }
 
-// grad[p] = sum over slabs.  One workgroup owns 32 consecutive parameters (one 128-byte line per slab
-// row); its 8 lane-groups stride over the slabs, partial sums meet in LDS in a fixed order.
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int n_slabs, int n_params,
-                                                           float *__restrict__ grad) {
+// ------------------------------------------------------------------------------------------
+// K2: TXP weight / bias gradients, one layer per blockIdx.y, waves fully independent
+// ------------------------------------------------------------------------------------------
+template <int CINL>
+__device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float *plane, float *dzs, int gwave,
+                                            int nwaves) {
+    constexpr int C = Cfg::C, P = Cfg::P;
+    constexpr int NCOL = 9 * CINL + 1, NTILE = (NCOL + 15) / 16;
+    const ModelLayout &L = a.lay;
+    const int V = a.V, lane = threadIdx.x & 63;
+    const int nq = lane & 15, kq = lane >> 4;
+    const int co_a = nq < P ? nq : P - 1;          // rows 12..15 of the tile are never written back
+    const bool is_out = layer == L.L;
+    int bcol[NTILE];
+    bool bone[NTILE];
+#pragma unroll
+    for (int tl = 0; tl < NTILE; ++tl) {
+        int col = tl * 16 + nq;
+        bone[tl] = col == NCOL - 1;
+        if (col > NCOL - 2) col = NCOL - 2;
+        bcol[tl] = col;
+    }
+    f32x4 acc[NTILE];
+#pragma unroll
+    for (int tl = 0; tl < NTILE; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int n = gwave; n < a.N; n += nwaves) {
+        int vi = a.num_peds ? a.num_peds[n] : V;
+        vi = vi < 0 ? 0 : (vi > V ? V : vi);
+        if (vi == 0) continue;
+        const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi;
+        const float *wsn = a.ws + n * a.ws_stride;
+        // stage a_l (whole zero-bordered plane, linear 16-byte copy) and dz_l ([P][npos])
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(wsn + ws_plane_off(L, V, layer));
+            float4 *dst = reinterpret_cast<float4 *>(plane);
+            for (int e = lane; e < (CINL * SC) >> 2; e += 64) dst[e] = src[e];
+            if (is_out) {
+                const float *dyn = a.dy + (int64_t)n * (C * P) * V;
+                for (int e = lane; e < P * npos; e += 64) {
+                    const int row = e / vi, w = e - row * vi;      // row = co*C + h
+                    dzs[e] = dyn[(int64_t)row * V + w];
+                }
+            } else {
+                const float4 *dsrc = reinterpret_cast<const float4 *>(a.dzg + ((int64_t)n * L.L + layer) * (P * C * V));
+                float4 *ddst = reinterpret_cast<float4 *>(dzs);
+                for (int e = lane; e < (P * npos + 3) >> 2; e += 64) ddst[e] = dsrc[e];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        int boff[NTILE];
+#pragma unroll
+        for (int tl = 0; tl < NTILE; ++tl) {
+            const int tap = bcol[tl] / CINL, ci = bcol[tl] - tap * CINL;
+            boff[tl] = ci * SC + (tap / 3 - 1) * SW + (tap % 3 - 1);
+        }
+        // this lane's position walks p = kq, kq+4, ... ; (h, w) advance without divisions
+        int h = kq / vi, w = kq - h * vi;
+        const int nsteps = (npos + 3) >> 2;
+        for (int s = 0; s < nsteps; ++s) {
+            const int p = 4 * s + kq;
+            const bool ok = p < npos;
+            const float av = ok ? dzs[co_a * npos + p] : 0.f;
+            const int offb = ok ? (h + 1) * SW + (w + 1) : SW + 1;
+#pragma unroll
+            for (int tl = 0; tl < NTILE; ++tl) {
+                const float bv = bone[tl] ? 1.f : plane[boff[tl] + offb];
+                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[tl], 0, 0, 0);
+            }
+            w += 4;
+            while (w >= vi) { w -= vi; ++h; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // one slab row per wave: [P][CINL][9] weights then [P] biases (the parameters' own order)
+    float *row = a.slab2 + wgrad_slab_base(layer, a.rows) + (int64_t)gwave * wgrad_row_len(layer);
+    if (kq < 3) {
+#pragma unroll
+        for (int tl = 0; tl < NTILE; ++tl) {
+            const int col = tl * 16 + nq;
+            if (col < NCOL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = 4 * kq + r;
+                    if (col == NCOL - 1) {
+                        row[P * CINL * 9 + co] = acc[tl][r];
+                    } else {
+                        const int tap = col / CINL, ci = col - tap * CINL;
+                        row[(co * CINL + ci) * 9 + tap] = acc[tl][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void txp_wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int wave = threadIdx.x >> 6;
+    const int per_wave = plane_slot(a.V) + ((Cfg::P * Cfg::C * a.V + 3) & ~3);
+    float *plane = sm + wave * per_wave;
+    float *dzs = plane + plane_slot(a.V);
+    const int layer = blockIdx.y;
+    const int gwave = blockIdx.x * WAVES + wave, nwaves = gridDim.x * WAVES;
+    if (layer == 0)
+        wgrad_layer<Cfg::T>(a, layer, plane, dzs, gwave, nwaves);
+    else
+        wgrad_layer<Cfg::P>(a, layer, plane, dzs, gwave, nwaves);
+}
+
+// ------------------------------------------------------------------------------------------
+// slab reduction: grad[p] = sum of the slab rows that hold parameter p, in row order
+// ------------------------------------------------------------------------------------------
+struct ReduceSeg {
+    int p0, len, rows, row_stride;
+    int64_t base;          // offset of (row 0, parameter p0) in the slab buffer
+};
+struct ReduceArgs {
+    ReduceSeg seg[kMaxTxp + 3];
+    int n_seg;
+    const float *slabs;
+    float *grad;
+    int n_params;
+};
+
+// One workgroup owns 32 consecutive parameters (one 128-byte line per slab row); its 8 lane-groups
+// stride over the rows, partial sums meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceArgs a) {
     __shared__ float part[8][32];
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int p = blockIdx.x * 32 + col;
     float s = 0.f;
-    if (p < n_params)
-        for (int k = grp; k < n_slabs; k += 8) s += slabs[(int64_t)k * n_params + p];
+    if (p < a.n_params) {
+        for (int q = 0; q < a.n_seg; ++q) {
+            const ReduceSeg g = a.seg[q];
+            if (p >= g.p0 && p < g.p0 + g.len) {
+                const float *src = a.slabs + g.base + (p - g.p0);
+                for (int k = grp; k < g.rows; k += 8) s += src[(int64_t)k * g.row_stride];
+            }
+        }
+    }
     part[grp][col] = s;
     __syncthreads();
-    if (grp == 0 && p < n_params) {
+    if (grp == 0 && p < a.n_params) {
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < 8; ++g) t += part[g][col];
-        grad[p] = t;
+        a.grad[p] = t;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int env_waves(const char *name, int dflt) {
+    if (const char *e = getenv(name)) {
+        const int w = atoi(e);
+        if (w == 1 || w == 2 || w == 4 || w == 8) return w;
+    }
+    return dflt;
 }
 
 static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves) {
     const int plane = Cfg::P * txp_sc(V);
     const int st = (2 * Cfg::C * (Cfg::T + 2) + Cfg::C * Cfg::T) * V;
-    const int two = 2 * plane > st ? 2 * plane : st;
-    const size_t fl = ((L.n_params + 3) & ~3) + (size_t)two + (size_t)Cfg::P * Cfg::C * V + (size_t)waves * kRedMax +
-                      kRedMax + (size_t)Cfg::C * V;
+    const int reg = plane > st ? plane : st;
+    const int n_small = L.n_blk_params + L.n_txp;
+    const size_t fl = ((n_small + 3) & ~3) + (size_t)reg + (size_t)Cfg::P * Cfg::C * V + (size_t)waves * kRedMax +
+                      kRedMax;
     return fl * sizeof(float);
 }
 
-static int bwd_waves(int V) {
-    int waves = V <= 12 ? 1 : (V <= 40 ? 2 : (V <= 80 ? 4 : 8));
-    if (const char *e = getenv("STG_BWD_WAVES")) {
-        const int w = atoi(e);
-        if (w == 1 || w == 2 || w == 4 || w == 8) waves = w;
-    }
-    return waves;
-}
+static int bwd_waves(int V) { return env_waves("STG_BWD_WAVES", V <= 12 ? 1 : (V <= 40 ? 2 : (V <= 80 ? 4 : 8))); }
 
 static int bwd_grid(const ModelLayout &L, int N, int V) {
     const int waves = bwd_waves(V);
     const size_t lds = bwd_lds_bytes(L, V, waves);
     if (lds > (size_t)kLdsBytes) return -1;
     int per_cu = (int)(kLdsBytes / lds);
-    const int by_waves = 16 / waves;          // keep <= 16 waves per CU resident
+    const int by_waves = 8 / waves > 0 ? 8 / waves : 1;   // 256-VGPR kernel: 2 waves per SIMD
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
     int grid = kNumCU * per_cu;
@@ -658,47 +743,106 @@ static int bwd_grid(const ModelLayout &L, int N, int V) {
     return grid < N ? grid : N;
 }
 
+// K2 launch geometry: waves per workgroup, workgroups per layer
+struct WgradGeom {
+    int waves, grid_x, rows;
+    size_t lds;
+};
+static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
+    const size_t per_wave = ((size_t)plane_slot(V) + ((Cfg::P * Cfg::C * V + 3) & ~3)) * sizeof(float);
+    if (per_wave > (size_t)kLdsBytes) return false;
+    int waves = env_waves("STG_WGRAD_WAVES", 4);
+    while (waves > 1 && per_wave * waves > (size_t)kLdsBytes) waves >>= 1;
+    g->waves = waves;
+    g->lds = per_wave * waves;
+    int per_cu = (int)(kLdsBytes / g->lds);
+    if (per_cu * waves > 8) per_cu = 8 / waves > 0 ? 8 / waves : 1;
+    int total = kNumCU * per_cu;                       // resident workgroups on the chip
+    int gx = total / (L.L + 1);
+    if (const char *e = getenv("STG_WGRAD_GRID")) {
+        const int v = atoi(e);
+        if (v > 0) gx = v;
+    }
+    if (gx < 1) gx = 1;
+    const int need = (N + waves - 1) / waves;
+    if (gx > need) gx = need;
+    g->grid_x = gx;
+    g->rows = gx * waves;
+    return true;
+}
+
+static int64_t bwd_scratch_floats(const ModelLayout &L, int N, int V) {
+    const int g1 = bwd_grid(L, N, V);
+    if (g1 < 0) return -1;
+    int64_t fl = (int64_t)g1 * (L.n_blk_params + L.n_txp);
+    fl = (fl + 3) & ~(int64_t)3;
+    if (L.n_txp > 0) {
+        WgradGeom g;
+        if (!wgrad_geom(L, N, V, &g)) return -1;
+        fl += wgrad_slab_base(L.L + 1, g.rows);
+        fl = (fl + 3) & ~(int64_t)3;
+        fl += (int64_t)N * L.L * (Cfg::P * Cfg::C * V);
+    }
+    return fl;
+}
+
 }  // namespace stg
 
 extern "C" {
 
-int64_t stg_model_bwd_slabs(const stg_model_desc *d, int N, int V) {
+int64_t stg_model_bwd_scratch_floats(const stg_model_desc *d, int N, int V) {
     stg::ModelLayout l;
     const int rc = stg::make_layout(d, &l);
     if (rc != STG_OK) return rc;
-    if (N <= 0 || V <= 0) return stg::fail(STG_EINVAL, "stg_model_bwd_slabs: N=%d V=%d", N, V);
-    const int g = stg::bwd_grid(l, N, V);
-    if (g < 0) return stg::fail(STG_ELDS, "stg_model_bwd: V=%d does not fit the LDS of one CU", V);
-    return g;
+    if (N <= 0 || V <= 0) return stg::fail(STG_EINVAL, "stg_model_bwd_scratch_floats: N=%d V=%d", N, V);
+    const int64_t fl = stg::bwd_scratch_floats(l, N, V);
+    if (fl < 0) return stg::fail(STG_ELDS, "stg_model_bwd: V=%d does not fit the LDS of one CU", V);
+    return fl;
 }
 
 int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
                   int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj, int64_t a_sn, const int32_t *num_peds,
-                  int N, int V, const float *dy, const float *ws, float *slabs, float *grad_params, float *dx,
+                  int N, int V, const float *dy, const float *ws, float *scratch, float *grad_params, float *dx,
                   void *stream) {
     using namespace stg;
     BwdArgs a{};
     const int rc = make_layout(d, &a.lay);
     if (rc != STG_OK) return rc;
-    STG_REQUIRE(params && buffers && x && adj && dy && ws && slabs && grad_params, STG_EINVAL,
+    const ModelLayout &L = a.lay;
+    STG_REQUIRE(params && buffers && x && adj && dy && ws && scratch && grad_params, STG_EINVAL,
                 "stg_model_bwd: null pointer");
     STG_REQUIRE(N >= 0 && V > 0, STG_EINVAL, "stg_model_bwd: bad sizes N=%d V=%d", N, V);
+    STG_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0,
+                STG_EINVAL, "stg_model_bwd: ws / scratch must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
     if (N == 0) {
-        hipError_t e = hipMemsetAsync(grad_params, 0, sizeof(float) * a.lay.n_params, st);
+        hipError_t e = hipMemsetAsync(grad_params, 0, sizeof(float) * L.n_params, st);
         if (e != hipSuccess) return hip_fail(e, "stg_model_bwd: memset");
         return STG_OK;
+    }
+    const int waves = bwd_waves(V);
+    const size_t lds = bwd_lds_bytes(L, V, waves);
+    STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_bwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
+                kLdsBytes);
+    const int grid = bwd_grid(L, N, V);
+    const int n_small = L.n_blk_params + L.n_txp;
+    // scratch carve (must match bwd_scratch_floats)
+    float *slab1 = scratch;
+    int64_t off = ((int64_t)grid * n_small + 3) & ~(int64_t)3;
+    float *slab2 = scratch + off;
+    WgradGeom wg{};
+    float *dzg = nullptr;
+    if (L.n_txp > 0) {
+        STG_REQUIRE(wgrad_geom(L, N, V, &wg), STG_ELDS, "stg_model_bwd: V=%d does not fit LDS (wgrad)", V);
+        off += wgrad_slab_base(L.L + 1, wg.rows);
+        off = (off + 3) & ~(int64_t)3;
+        dzg = scratch + off;
     }
     a.params = params; a.buffers = buffers; a.x = x;
     a.x_sn = x_sn; a.x_sc = x_sc; a.x_st = x_st; a.x_sv = x_sv;
     a.adj = adj; a.a_sn = a_sn; a.num_peds = num_peds; a.N = N; a.V = V;
-    a.dy = dy; a.ws = ws; a.ws_stride = ws_floats_per_scene(a.lay, V); a.slabs = slabs; a.dx = dx;
+    a.dy = dy; a.ws = ws; a.ws_stride = ws_floats_per_scene(L, V); a.slab1 = slab1; a.dzg = dzg; a.dx = dx;
     if (const char *e = getenv("STG_DEBUG_SKIP")) a.debug_skip = atoi(e);
-    const int waves = bwd_waves(V);
-    const size_t lds = bwd_lds_bytes(a.lay, V, waves);
-    STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_bwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
-                kLdsBytes);
-    const int grid = bwd_grid(a.lay, N, V);
 #define STG_LAUNCH_BWD(W)                                                                                    \
     do {                                                                                                     \
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&model_bwd_kernel<W>),            \
@@ -713,9 +857,44 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         default: STG_LAUNCH_BWD(8); break;
     }
 #undef STG_LAUNCH_BWD
-    STG_LAUNCH_CHECK("stg_model_bwd");
-    const int np = a.lay.n_params;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((np + 31) / 32), dim3(256), 0, st, slabs, grid, np, grad_params);
+    STG_LAUNCH_CHECK("stg_model_bwd: K1");
+
+    ReduceArgs r{};
+    r.slabs = scratch;
+    r.grad = grad_params;
+    r.n_params = L.n_params;
+    r.seg[r.n_seg++] = ReduceSeg{0, L.n_blk_params, grid, n_small, 0};
+    if (L.n_txp > 0) {
+        r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, grid, n_small, (int64_t)L.n_blk_params};
+        WgradArgs w{};
+        w.lay = L; w.num_peds = num_peds; w.N = N; w.V = V; w.dy = dy; w.ws = ws; w.dzg = dzg;
+        w.ws_stride = a.ws_stride; w.slab2 = slab2; w.rows = wg.rows;
+        if (!(a.debug_skip & 1)) {
+            const dim3 g2(wg.grid_x, L.L + 1);
+#define STG_LAUNCH_WG(W)                                                                                     \
+    do {                                                                                                     \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_wgrad_kernel<W>),            \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg.lds);        \
+        if (e_ != hipSuccess) return hip_fail(e_, "stg_model_bwd: hipFuncSetAttribute (wgrad)");             \
+        hipLaunchKernelGGL(txp_wgrad_kernel<W>, g2, dim3(W * 64), wg.lds, st, w);                            \
+    } while (0)
+            switch (wg.waves) {
+                case 1: STG_LAUNCH_WG(1); break;
+                case 2: STG_LAUNCH_WG(2); break;
+                case 4: STG_LAUNCH_WG(4); break;
+                default: STG_LAUNCH_WG(8); break;
+            }
+#undef STG_LAUNCH_WG
+            STG_LAUNCH_CHECK("stg_model_bwd: K2");
+        }
+        const int64_t s2 = slab2 - scratch;
+        for (int l = 0; l <= L.L; ++l) {
+            const int p0 = l == L.L ? L.out_w : L.txp_w[l];
+            r.seg[r.n_seg++] = ReduceSeg{p0, wgrad_row_len(l), (a.debug_skip & 1) ? 0 : wg.rows, wgrad_row_len(l),
+                                         s2 + wgrad_slab_base(l, wg.rows)};
+        }
+    }
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((L.n_params + 31) / 32), dim3(256), 0, st, r);
     STG_LAUNCH_CHECK("stg_model_bwd: reduce_slabs");
     return STG_OK;
 }

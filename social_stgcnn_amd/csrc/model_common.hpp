@@ -32,19 +32,17 @@ struct ModelLayout {
     int32_t txp_w[kMaxTxp], txp_b[kMaxTxp], out_w, out_b, prelus;
     int32_t n_params, n_buffers, stat_floats;
     int32_t ws_hdr_floats;          // fixed part of the per-scene workspace
-    int32_t ws_a[kMaxTxp + 1];      // a_0 (T*C rows) .. a_L (P*C rows), units of V floats
-    int32_t ws_z[kMaxTxp];          // z_0 .. z_{L-1}
-    int32_t ws_units;               // total units of V floats
+    int32_t ws_z[kMaxTxp];          // z_0 .. z_{L-1} (pre-activation, [P][C][vi]), units of V floats
+    int32_t ws_units;               // total units of V floats (block arrays + z)
+    int32_t n_planes;               // a_0 .. a_L saved as zero-bordered planes [P][txp_sc(V)] behind the units
+    // small-parameter map of the backward: block parameters [0, n_blk_params) and the PReLU slopes
+    int32_t n_blk_params;
     int32_t use_mdn, bn_mode;
     float eps, momentum;
 };
 
 // Fills `lay` from the public descriptor; returns STG_OK or an error code (message in last_error).
 int make_layout(const stg_model_desc *d, ModelLayout *lay);
-
-inline int64_t ws_floats_per_scene(const ModelLayout &l, int V) {
-    return (int64_t)l.ws_hdr_floats + (int64_t)l.ws_units * V;
-}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -54,6 +52,17 @@ __host__ __device__ inline int txp_sw(int vi) { return vi + 2; }
 __host__ __device__ inline int txp_sc(int vi) {
     const int raw = (Cfg::C + 2) * (vi + 2);
     return raw + ((16 - (raw & 31)) & 31);
+}
+// floats of one saved plane slot (sized for the padded batch V; a scene uses P*txp_sc(vi) of it)
+__host__ __device__ inline int plane_slot(int V) { return Cfg::P * txp_sc(V); }
+
+// offset (floats, from the scene's workspace base, 16-byte aligned) of saved plane a_l
+__host__ __device__ inline int64_t ws_plane_off(const ModelLayout &l, int V, int idx) {
+    const int64_t arrays = ((int64_t)l.ws_hdr_floats + (int64_t)l.ws_units * V + 3) & ~(int64_t)3;
+    return arrays + (int64_t)idx * plane_slot(V);
+}
+__host__ __device__ inline int64_t ws_floats_per_scene(const ModelLayout &l, int V) {
+    return ws_plane_off(l, V, l.n_planes);
 }
 
 }  // namespace stg

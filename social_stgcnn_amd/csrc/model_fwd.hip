@@ -60,7 +60,7 @@ __device__ __forceinline__ void block_sum(float (&v)[K], float *red) {
 template <int CIN, int WAVES>
 __device__ void stgcn_block_fwd(const FwdArgs &a, const BlockLayout &b, int n, int vi, const float *X, float *G,
                                 float *H, float *cs, float *red, float *wsn, float *statn, bool to_txp,
-                                float *plane, float *yblock) {
+                                float *plane, float *yblock, bool save_s) {
     constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, NT = WAVES * 64;
     const int tid = threadIdx.x, V = a.V;
     const int cnt = T * vi;
@@ -284,7 +284,7 @@ __device__ void stgcn_block_fwd(const FwdArgs &a, const BlockLayout &b, int n, i
                 }
                 const float s = (a.lay.use_mdn || u > 0.f) ? u : ao * u;
                 H[i] = s;
-                if (wsn) wsa[(int64_t)b.ws_s * V + i] = s;
+                if (wsn && save_s) wsa[(int64_t)b.ws_s * V + i] = s;
                 if (to_txp) {
                     // v.view(N, T, C, V) (model.py:187): flat plane index f = c*T+t -> (f / C, f % C)
                     const int f = c * T + t, ch = f / C, row = f - ch * C;
@@ -315,8 +315,7 @@ __device__ __forceinline__ void txp_load_weights(const float *__restrict__ W, fl
 // kind: 0 = hidden layer without residual (layer 0), 1 = hidden layer with residual, 2 = output conv
 template <int CINL, int WAVES>
 __device__ void txp_layer_fwd(const float *__restrict__ W, const float *__restrict__ bias, float alpha, int kind,
-                              const float *in, float *out, int vi, int V, float *zsave, float *asave,
-                              float *yout) {
+                              const float *in, float *out, int vi, int V, float *zsave, float *yout) {
     constexpr int C = Cfg::C, P = Cfg::P, KS = CINL * 9 / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nq = lane & 15, kq = lane >> 4;
@@ -369,10 +368,7 @@ __device__ void txp_layer_fwd(const float *__restrict__ W, const float *__restri
                     float av = z > 0.f ? z : alpha * z;
                     if (kind == 1) av += in[li];
                     out[li] = av;
-                    if (zsave) {
-                        zsave[flat] = z;
-                        asave[flat] = av;
-                    }
+                    if (zsave) zsave[flat] = z;
                 }
             }
         }
@@ -427,10 +423,10 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a) 
             float *yb = (last && L.n_txp == 0) ? yn : nullptr;
             if (L.blk[j].cin == Cfg::CIN0)
                 stgcn_block_fwd<Cfg::CIN0, WAVES>(a, L.blk[j], n, vi, X, G, H, cs, red, wsn, statn,
-                                                  last && L.n_txp > 0, bufA, yb);
+                                                  last && L.n_txp > 0, bufA, yb, !last);
             else
                 stgcn_block_fwd<Cfg::C, WAVES>(a, L.blk[j], n, vi, X, G, H, cs, red, wsn, statn,
-                                               last && L.n_txp > 0, bufA, yb);
+                                               last && L.n_txp > 0, bufA, yb, !last);
             float *tmp = X; X = H; H = tmp;      // block output becomes the next block's input
         }
         if (L.n_txp == 0 || (a.debug_skip & 16)) continue;
@@ -440,20 +436,27 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a) 
         __syncthreads();
         const float *Pm = a.params;
         float *in = bufA, *out = bufB;
+        // a_l leaves as a whole zero-bordered plane (linear 16-byte stores): the weight-gradient kernel
+        // stages it back into LDS with a linear copy
+        auto save_plane = [&](const float *pl, int idx) {
+            if (!wsn) return;
+            float4 *dst = reinterpret_cast<float4 *>(wsn + ws_plane_off(L, V, idx));
+            const float4 *src = reinterpret_cast<const float4 *>(pl);
+            for (int e = tid; e < (P * SC) >> 2; e += NT) dst[e] = src[e];
+        };
+        save_plane(in, 0);
         for (int l = 0; l < L.L; ++l) {
             float *zs = wsn ? wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V : nullptr;
-            float *as = wsn ? wsn + L.ws_hdr_floats + (int64_t)L.ws_a[l + 1] * V : nullptr;
             const float alpha = Pm[L.prelus + l];
             if (l == 0)
-                txp_layer_fwd<Cfg::T, WAVES>(Pm + L.txp_w[0], Pm + L.txp_b[0], alpha, 0, in, out, vi, V, zs, as,
-                                             nullptr);
+                txp_layer_fwd<Cfg::T, WAVES>(Pm + L.txp_w[0], Pm + L.txp_b[0], alpha, 0, in, out, vi, V, zs, nullptr);
             else
-                txp_layer_fwd<Cfg::P, WAVES>(Pm + L.txp_w[l], Pm + L.txp_b[l], alpha, 1, in, out, vi, V, zs, as,
-                                             nullptr);
+                txp_layer_fwd<Cfg::P, WAVES>(Pm + L.txp_w[l], Pm + L.txp_b[l], alpha, 1, in, out, vi, V, zs, nullptr);
             __syncthreads();
             float *tmp = in; in = out; out = tmp;
+            save_plane(in, l + 1);
         }
-        txp_layer_fwd<Cfg::P, WAVES>(Pm + L.out_w, Pm + L.out_b, 0.f, 2, in, out, vi, V, nullptr, nullptr, yn);
+        txp_layer_fwd<Cfg::P, WAVES>(Pm + L.out_w, Pm + L.out_b, 0.f, 2, in, out, vi, V, nullptr, yn);
     }
 }
 

@@ -73,10 +73,10 @@ int make_layout(const stg_model_desc *d, ModelLayout *lay) {
         l.out_w = p; p += P * P * 9;
         l.out_b = p; p += P;
         l.prelus = p; p += l.n_txp;
-        l.ws_a[0] = l.blk[l.n_blocks - 1].ws_s;     // a_0 is the last block's output (a view, model.py:187)
-        for (int q = 1; q <= l.L; ++q) { l.ws_a[q] = u; u += P * C; }
         for (int q = 0; q < l.L; ++q) { l.ws_z[q] = u; u += P * C; }
+        l.n_planes = l.L + 1;                        // a_0 (the last block's output, model.py:187) .. a_L
     }
+    l.n_blk_params = l.n_txp > 0 ? l.txp_w[0] : p;
     l.n_params = p;
     l.n_buffers = b;
     l.stat_floats = s;

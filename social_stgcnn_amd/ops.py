@@ -257,10 +257,10 @@ class _FusedModel(torch.autograd.Function):
         dy = dy.contiguous()
         n, cin, t, v = x.shape
         np_ = int(L.stg_model_param_count(ctypes.byref(desc)))
-        n_slabs = L.stg_model_bwd_slabs(ctypes.byref(desc), n, v)
-        if n_slabs < 0:
-            check(int(n_slabs), "stg_model_bwd_slabs")
-        slabs = torch.empty(int(n_slabs) * np_, device=x.device, dtype=torch.float32)
+        n_scratch = L.stg_model_bwd_scratch_floats(ctypes.byref(desc), n, v)
+        if n_scratch < 0:
+            check(int(n_scratch), "stg_model_bwd_scratch_floats")
+        slabs = torch.empty(int(n_scratch), device=x.device, dtype=torch.float32)
         grad = torch.empty(np_, device=x.device, dtype=torch.float32)
         dx = torch.empty((n, cin, t, v), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         sn, sc, st, sv = x.stride()

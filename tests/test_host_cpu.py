@@ -1,0 +1,88 @@
+"""CPU: host logic -- ingest against the reference TrajectoryDataset fixture, group semantics,
+and the data-parallel pieces on a world-size-2 gloo group."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+
+def test_ingest_matches_reference_dataset():
+    """N1: load_windows on the raw eth/test file == the reference TrajectoryDataset (fixture)."""
+    from social_stgcnn_amd import data
+    g = load_golden("eth_test_windows.npz")
+    w = data.load_windows(os.path.join(GOLDEN, "data", "eth_test"), 8, 12, 1)
+    assert len(w) == 70 and int(w.num_peds.sum()) == 181 and int(w.num_peds.max()) == 5
+    assert np.array_equal(w.num_peds, g["num_peds"])
+    assert np.array_equal(w.seq.astype(np.float32), g["seq"])
+    assert np.array_equal(w.seq_rel.astype(np.float32), g["seq_rel"])
+    assert np.array_equal(w.non_linear.astype(np.float32), g["non_linear"])
+    assert np.array_equal(w.loss_mask.astype(np.float32), g["loss_mask"])
+    assert w.max_peds_in_frame == int(g["max_peds_in_frame"])
+    obs_rel, pred_rel, obs_abs, pred_abs, peds = data.pad_batch(w, np.arange(4))
+    assert obs_rel.shape == (4, 8, int(peds.max()), 2) and pred_rel.shape[1] == 12
+    assert np.array_equal(obs_rel[0, :, :peds[0]], g["v_obs0"])          # V_obs of the first window
+    assert np.array_equal(pred_rel[0, :, :peds[0]], g["v_tr0"])
+    assert np.all(obs_rel[0, :, peds[0]:] == 0)
+
+
+def test_group_semantics():
+    from social_stgcnn_amd.trainer import group_bounds, group_weights
+    from oracle import stgcnn_oracle as O
+    for n, b in ((40, 16), (2785, 128), (256, 128), (5, 8), (130, 128)):
+        assert group_bounds(n, b) == O.group_boundaries(n, b)
+    w = group_weights(16, 16)
+    assert float(w[-1]) == 0 and np.allclose(w[:-1].numpy(), 1 / 16)
+
+
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from social_stgcnn_amd.trainer import allreduce_flat, broadcast_module, fold_bn_across_ranks
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    # gradient all-reduce: one flat buffer, sum over ranks
+    g = torch.arange(7563, dtype=torch.float32) * (rank + 1)
+    allreduce_flat(g)
+    assert torch.equal(g, torch.arange(7563, dtype=torch.float32) * sum(r + 1 for r in range(world)))
+    # BatchNorm fold: every rank folds its own scenes, the cross-rank fold equals one sequential pass
+    m = 0.1
+    before = torch.linspace(-1, 1, 30)
+    gen = torch.Generator().manual_seed(7)
+    stats = torch.randn(world, 5 + 3, 30, generator=gen)              # same on all ranks
+    n_local = 5 + 3 * rank                                            # ragged shard sizes
+    after = before.clone()
+    for i in range(n_local):
+        after = (1 - m) * after + m * stats[rank, i]
+    folded = fold_bn_across_ranks(before, after, n_local, m)
+    ref = before.clone()
+    for r in range(world):
+        for i in range(5 + 3 * r):
+            ref = (1 - m) * ref + m * stats[r, i]
+    assert torch.allclose(folded, ref, rtol=1e-5, atol=1e-6), float((folded - ref).abs().max())
+    # initial broadcast
+    lin = torch.nn.Linear(4, 3)
+    broadcast_module(lin)
+    w = [torch.empty_like(lin.weight) for _ in range(world)]
+    dist.all_gather(w, lin.weight.data)
+    assert all(torch.equal(w[0], t) for t in w)
+    dist.barrier()
+    dist.destroy_process_group()
+    out.put(rank)
+
+
+def test_data_parallel_pieces_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(out.get(timeout=5) for _ in range(2)) == [0, 1]

@@ -35,7 +35,7 @@ def test_layout_queries_match_reference_counts(L):
     assert L.stg_model_param_count(ctypes.byref(d)) == 7563          # 7,563 parameters
     assert L.stg_model_buffer_count(ctypes.byref(d)) == 30           # 3 BatchNorm x (mean, var) x 5
     assert L.stg_model_stat_floats(ctypes.byref(d)) == 30
-    assert L.stg_model_ws_floats(ctypes.byref(d), 32) == 64 + 32 * (16 + 8 + 40 + 40 + 40 + 4 * 60 + 4 * 60)
+    assert L.stg_model_ws_floats(ctypes.byref(d), 32) == 64 + 32 * (16 + 8 + 40 + 40 + 40 + 4 * 60) + 5 * 12 * 240
     d2 = ops.make_desc(2, 3, 2, 5, 8, 12, 3, 2, False, False)
     # second block: identity residual -> no residual conv / BN parameters
     blk0 = 10 + 5 + 10 + 1 + 75 + 5 + 10 + 10 + 5 + 10 + 1
@@ -55,8 +55,8 @@ def test_invalid_arguments_return_status_not_abort(L):
     assert b"seq_len" in L.stg_last_error()
     assert L.stg_selftest_mfma(None, None, 3, None, None) == -1
     d = ops.make_desc(1, 5, 2, 5, 8, 12, 3, 2, False, True)
-    assert L.stg_model_bwd_slabs(ctypes.byref(d), 2048, 32) > 0
-    assert L.stg_model_bwd_slabs(ctypes.byref(d), 16, 400) == -3     # does not fit 160 KiB of LDS
+    assert L.stg_model_bwd_scratch_floats(ctypes.byref(d), 2048, 32) > 0
+    assert L.stg_model_bwd_scratch_floats(ctypes.byref(d), 16, 400) == -3     # does not fit 160 KiB of LDS
 
 
 def test_product_never_imports_the_oracle():
