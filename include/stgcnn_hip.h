@@ -33,7 +33,7 @@ extern "C" {
 #define STG_EUNSUPPORTED (-2) /* configuration outside what the kernels are built for      */
 #define STG_ELDS (-3)        /* scene too large for the 160 KiB LDS of one CU             */
 
-#define STG_ABI_VERSION 1
+#define STG_ABI_VERSION 2
 #define STG_MAX_BLOCKS 4     /* st_gcn blocks in one fused model                          */
 
 int stg_abi_version(void);
@@ -116,17 +116,21 @@ int64_t stg_model_ws_floats(const stg_model_desc *d, int V);
 /* Per-scene batch statistics the forward emits in bn_mode 1: (N, stat_floats) =
  * per block, per BatchNorm: mean[C], unbiased var[C].                                           */
 int64_t stg_model_stat_floats(const stg_model_desc *d);
+/* Scratch floats stg_model_fwd needs (hand-off between its block kernel and its TXP-CNN kernel; 0 when
+ * one kernel does both). */
+int64_t stg_model_fwd_scratch_floats(const stg_model_desc *d, int N, int V);
 /* Scratch floats stg_model_bwd needs (partial-gradient slab rows of its kernels + the dz hand-off
  * between the input-gradient kernel and the weight-gradient kernel). */
 int64_t stg_model_bwd_scratch_floats(const stg_model_desc *d, int N, int V);
 
 /* x (N,c_in,t_obs,V) strided; adj (N,t_obs,V,V), batch stride a_sn (0 = shared);
  * y: (N,c_out,t_pred,V) when n_txpcnn>0, else the block output (N,c_out,t_obs,V).
- * ws: N * stg_model_ws_floats floats or NULL (inference).  stats: N * stg_model_stat_floats or NULL. */
+ * ws: N * stg_model_ws_floats floats (16-byte aligned) or NULL (inference).  stats: N * stg_model_stat_floats
+ * or NULL.  scratch: stg_model_fwd_scratch_floats floats, 16-byte aligned (may be NULL when that is 0).     */
 int stg_model_fwd(const stg_model_desc *d, const float *params, const float *buffers,
                   const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv,
                   const float *adj, int64_t a_sn, const int32_t *num_peds, int N, int V,
-                  float *y, float *ws, float *stats, void *stream);
+                  float *y, float *ws, float *stats, float *scratch, void *stream);
 /* dy like y.  grad_params (param_count) is OVERWRITTEN with the gradient summed over the batch;
  * dx (N,c_in,t_obs,V) may be NULL.  scratch: stg_model_bwd_scratch_floats floats, 16-byte aligned
  * (ws must be 16-byte aligned too).                                                               */

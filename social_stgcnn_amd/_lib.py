@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libstgcnn_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_f = ctypes.c_void_p          # device pointers travel as void*
 c_i = ctypes.c_int
@@ -41,9 +41,10 @@ _SIGNATURES = {
     "stg_model_buffer_count": (c_l, [ctypes.POINTER(ModelDesc)]),
     "stg_model_ws_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i]),
     "stg_model_stat_floats": (c_l, [ctypes.POINTER(ModelDesc)]),
+    "stg_model_fwd_scratch_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i, c_i]),
     "stg_model_bwd_scratch_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i, c_i]),
     "stg_model_fwd": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_f, c_l, c_l, c_l, c_l, c_f, c_l, c_f, c_i, c_i,
-                            c_f, c_f, c_f, c_f]),
+                            c_f, c_f, c_f, c_f, c_f]),
     "stg_model_bwd": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_f, c_l, c_l, c_l, c_l, c_f, c_l, c_f, c_i, c_i,
                             c_f, c_f, c_f, c_f, c_f, c_f]),
     "stg_bn_fold": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_i, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f]),

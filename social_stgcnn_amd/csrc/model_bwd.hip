@@ -19,6 +19,7 @@
 //     the N/16 accumulator tiles in VGPRs for the whole launch -- no barriers, no atomics.
 //  reduce_slabs_kernel      sums the slab rows of K1 and K2 into the flat gradient in a fixed order.
 #include "model_common.hpp"
+#include "txp_wave.hpp"
 
 namespace stg {
 
@@ -35,6 +36,7 @@ struct BwdArgs {
     float *slab1;     // K1 slab rows: [gridDim.x][n_blk_params + n_txp]
     float *dzg;       // dz_l of the hidden TXP layers for K2: [N][L][P*C*V]
     float *dx;
+    const float *da0; // non-null: the TXP chain ran in txp_bwd_wave_kernel; d(block output) comes from here
     int debug_skip;   // timing-only diagnostic (STG_DEBUG_SKIP): 1 wgrad, 2 dgrad, 4 st_gcn -- wrong results
 };
 
@@ -47,6 +49,7 @@ struct WgradArgs {
     int64_t ws_stride;
     float *slab2;          // [layer 0..L][rows][row_len(layer)] packed, see wgrad_slab_base()
     int rows;              // slab rows per layer = gridDim.x * WAVES
+    int debug_skip;        // timing-only diagnostic: 64 skip staging, 128 skip the MFMA loop
 };
 
 // slab geometry of K2: layer 0 has c_in = T, layers 1..L (L = output conv) have c_in = P
@@ -486,33 +489,63 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
         const int out_rows = L.n_txp > 0 ? C * P : C * T;
         const float *dyn = a.dy + (int64_t)n * out_rows * V;
         __syncthreads();
-        if (L.n_txp > 0) {
+        if (a.da0) {
+            const float *src = a.da0 + (int64_t)n * (C * T * V);
+            for (int e = tid; e < C * T * vi; e += NT) dcur[e] = src[e];
+            __syncthreads();
+        } else if (L.n_txp > 0) {
             // ---- TXP-CNN backward (input-gradient chain) -------------------------------------------
             for (int e = tid; e < P * SC; e += NT) dzb[e] = 0.f;
             __syncthreads();
             for (int l = L.L; l >= 0; --l) {
                 const bool is_out = l == L.L;
                 if (is_out) {
-                    for (int e = tid; e < P * npos; e += NT) {
-                        const int ch = e / npos, p = e - ch * npos, h = p / vi, w = p - h * vi;
-                        dzb[ch * SC + (h + 1) * SW + (w + 1)] = dyn[(int64_t)(ch * C + h) * V + w];
+                    constexpr int U = 4;
+                    for (int e0 = tid; e0 < P * npos; e0 += NT * U) {
+                        float dv[U];
+                        int li[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int e = e0 + u * NT;
+                            const int ec = e < P * npos ? e : 0;
+                            const int ch = ec / npos, p = ec - ch * npos, h = p / vi, w = p - h * vi;
+                            li[u] = ch * SC + (h + 1) * SW + (w + 1);
+                            dv[u] = dyn[(int64_t)(ch * C + h) * V + w];
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            if (e0 + u * NT < P * npos) dzb[li[u]] = dv[u];
                     }
                     __syncthreads();
                 } else {
                     const float *zl = wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V;
-                    float *dzo = a.dzg + ((int64_t)n * L.L + l) * (P * C * V);
+                    float *dzo = a.dzg + ((int64_t)n * L.L + l) * dz_slot(V);
+                    const int dzs_ld = dz_stride(vi);
                     const float alpha = Pm[L.prelus + l];
                     float s[1] = {0.f};
-                    for (int e = tid; e < P * npos; e += NT) {
-                        const int ch = e / npos, p = e - ch * npos, h = p / vi, w = p - h * vi;
-                        const float z = zl[e], d = dcur[e];
-                        float dz = d;
-                        if (!(z > 0.f)) {
-                            dz = alpha * d;
-                            s[0] = fmaf(d, z, s[0]);
+                    constexpr int U = 4;                       // z loads in flight per lane
+                    for (int e0 = tid; e0 < P * npos; e0 += NT * U) {
+                        float zv[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int e = e0 + u * NT;
+                            zv[u] = e < P * npos ? zl[e] : 1.f;
                         }
-                        dzb[ch * SC + (h + 1) * SW + (w + 1)] = dz;
-                        dzo[e] = dz;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int e = e0 + u * NT;
+                            if (e < P * npos) {
+                                const int ch = e / npos, p = e - ch * npos, h = p / vi, w = p - h * vi;
+                                const float z = zv[u], d = dcur[e];
+                                float dz = d;
+                                if (!(z > 0.f)) {
+                                    dz = alpha * d;
+                                    s[0] = fmaf(d, z, s[0]);
+                                }
+                                dzb[ch * SC + (h + 1) * SW + (w + 1)] = dz;
+                                dzo[ch * dzs_ld + p] = dz;
+                            }
+                        }
                     }
                     block_reduce<1, WAVES>(s, red, tot);
                     if (tid == 0) gsm[L.n_blk_params + l] += tot[0];
@@ -555,6 +588,20 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
 // ------------------------------------------------------------------------------------------
 // K2: TXP weight / bias gradients, one layer per blockIdx.y, waves fully independent
 // ------------------------------------------------------------------------------------------
+// Linear global -> LDS copy of `nvec` 16-byte vectors by ONE wave with LDS-DMA (global_load_lds_dwordx4:
+// every instruction moves 1 KiB, no VGPR round trip, all of them in flight at once).  The caller waits
+// with s_waitcnt vmcnt(0) before reading the image.
+__device__ __forceinline__ void wave_dma_copy(const float *__restrict__ src, float *lds_dst, int nvec) {
+    const int lane = threadIdx.x & 63;
+    for (int i = 0; i * 64 < nvec; ++i) {
+        const int e = i * 64 + lane;
+        if (e < nvec)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + 4 * e),
+                (__attribute__((address_space(3))) void *)(lds_dst + 256 * i), 16, 0, 0);
+    }
+}
+
 template <int CINL>
 __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float *plane, float *dzs, int gwave,
                                             int nwaves) {
@@ -578,51 +625,96 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
 #pragma unroll
     for (int tl = 0; tl < NTILE; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    gwave = __builtin_amdgcn_readfirstlane(gwave);
     for (int n = gwave; n < a.N; n += nwaves) {
         int vi = a.num_peds ? a.num_peds[n] : V;
-        vi = vi < 0 ? 0 : (vi > V ? V : vi);
+        vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));    // wave-uniform
         if (vi == 0) continue;
-        const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi;
+        const int SW = txp_sw(vi), npos = C * vi;
         const float *wsn = a.ws + n * a.ws_stride;
-        // stage a_l (whole zero-bordered plane, linear 16-byte copy) and dz_l ([P][npos])
-        {
-            const float4 *src = reinterpret_cast<const float4 *>(wsn + ws_plane_off(L, V, layer));
-            float4 *dst = reinterpret_cast<float4 *>(plane);
-            for (int e = lane; e < (CINL * SC) >> 2; e += 64) dst[e] = src[e];
-            if (is_out) {
-                const float *dyn = a.dy + (int64_t)n * (C * P) * V;
-                for (int e = lane; e < P * npos; e += 64) {
-                    const int row = e / vi, w = e - row * vi;      // row = co*C + h
-                    dzs[e] = dyn[(int64_t)row * V + w];
+        // stage a_l (whole zero-bordered plane, position-major [(C+2)*SW][P]) and dz_l ([P][ld]) with LDS-DMA
+        const int ld = dz_stride(vi);
+        if (a.debug_skip & 64) {
+        } else if (is_out) {
+            wave_dma_copy(wsn + ws_plane_off(L, V, layer), plane, ((C + 2) * SW * P + 3) >> 2);
+            // the output conv's dz is dy itself: (C*P) rows of V floats, vi valid -> [P][ld]
+            const float *dyn = a.dy + (int64_t)n * (C * P) * V;
+            constexpr int U = 8;
+            for (int e0 = lane; e0 < P * npos; e0 += 64 * U) {
+                float dv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = e0 + 64 * u;
+                    const int ec = e < P * npos ? e : 0;
+                    const int row = ec / vi, w = ec - row * vi;        // row = co*C + h
+                    dv[u] = dyn[(int64_t)row * V + w];
                 }
-            } else {
-                const float4 *dsrc = reinterpret_cast<const float4 *>(a.dzg + ((int64_t)n * L.L + layer) * (P * C * V));
-                float4 *ddst = reinterpret_cast<float4 *>(dzs);
-                for (int e = lane; e < (P * npos + 3) >> 2; e += 64) ddst[e] = dsrc[e];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = e0 + 64 * u;
+                    if (e < P * npos) {
+                        const int co = e / npos;
+                        dzs[co * ld + (e - co * npos)] = dv[u];
+                    }
+                }
             }
+        } else {
+            wave_dma_copy(wsn + ws_plane_off(L, V, layer), plane, ((C + 2) * SW * P + 3) >> 2);
+            wave_dma_copy(a.dzg + ((int64_t)n * L.L + layer) * dz_slot(V), dzs, (P * ld + 3) >> 2);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         int boff[NTILE];
 #pragma unroll
         for (int tl = 0; tl < NTILE; ++tl) {
             const int tap = bcol[tl] / CINL, ci = bcol[tl] - tap * CINL;
-            boff[tl] = ci * SC + (tap / 3 - 1) * SW + (tap % 3 - 1);
+            boff[tl] = ((tap / 3 - 1) * SW + (tap % 3 - 1)) * P + ci;
         }
-        // this lane's position walks p = kq, kq+4, ... ; (h, w) advance without divisions
-        int h = kq / vi, w = kq - h * vi;
-        const int nsteps = (npos + 3) >> 2;
-        for (int s = 0; s < nsteps; ++s) {
+        // K loop over the scene's positions, 4 per MFMA; this lane walks p = kq, kq+4, ...
+        // Two steps per iteration: all 16 operand reads are issued before the 14 MFMAs, so the LDS latency
+        // of iteration i+1 hides behind the matrix pipe still draining iteration i.
+        const int nsteps = (a.debug_skip & 128) ? 0 : (npos + 3) >> 2;
+        const int nfull = vi >= 4 ? ((a.debug_skip & 128) ? 0 : (npos >> 2)) : 0;   // steps without a K tail
+        int w = kq;                                  // vi >= 4 on the fast path: h = 0
+        int pos_off = (SW + 1 + kq) * P;             // ((h+1)*SW + (w+1)) * P
+        int a_idx = co_a * ld + kq;
+        auto advance = [&]() {                       // p += 4 (vi >= 4: at most one row wrap)
+            w += 4;
+            const bool wrap = w >= vi;
+            w -= wrap ? vi : 0;
+            pos_off += wrap ? 6 * P : 4 * P;         // a wrap skips the two border columns (SW = vi + 2)
+            a_idx += 4;
+        };
+        int s = 0;
+        for (; s + 2 <= nfull; s += 2) {
+            float av0 = dzs[a_idx], raw0[NTILE];
+#pragma unroll
+            for (int tl = 0; tl < NTILE; ++tl) raw0[tl] = plane[boff[tl] + pos_off];
+            advance();
+            float av1 = dzs[a_idx], raw1[NTILE];
+#pragma unroll
+            for (int tl = 0; tl < NTILE; ++tl) raw1[tl] = plane[boff[tl] + pos_off];
+            advance();
+#pragma unroll
+            for (int tl = 0; tl < NTILE; ++tl)
+                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bone[tl] ? 1.f : raw0[tl], acc[tl], 0, 0, 0);
+#pragma unroll
+            for (int tl = 0; tl < NTILE; ++tl)
+                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bone[tl] ? 1.f : raw1[tl], acc[tl], 0, 0, 0);
+        }
+        // remaining steps (odd count, K tail p >= npos, or tiny scenes with vi < 4): checked, generic
+        for (; s < nsteps; ++s) {
             const int p = 4 * s + kq;
             const bool ok = p < npos;
-            const float av = ok ? dzs[co_a * npos + p] : 0.f;
-            const int offb = ok ? (h + 1) * SW + (w + 1) : SW + 1;
+            const int pc = ok ? p : 0;
+            const int hh = pc / vi, ww = pc - hh * vi;
+            const float av = ok ? dzs[co_a * ld + pc] : 0.f;
+            const int offb = ((hh + 1) * SW + (ww + 1)) * P;
 #pragma unroll
             for (int tl = 0; tl < NTILE; ++tl) {
-                const float bv = bone[tl] ? 1.f : plane[boff[tl] + offb];
-                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[tl], 0, 0, 0);
+                const float raw = plane[boff[tl] + offb];
+                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bone[tl] ? 1.f : raw, acc[tl], 0, 0, 0);
             }
-            w += 4;
-            while (w >= vi) { w -= vi; ++h; }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -652,7 +744,7 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void txp_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int wave = threadIdx.x >> 6;
-    const int per_wave = plane_slot(a.V) + ((Cfg::P * Cfg::C * a.V + 3) & ~3);
+    const int per_wave = plane_slot(a.V) + dz_slot(a.V);
     float *plane = sm + wave * per_wave;
     float *dzs = plane + plane_slot(a.V);
     const int layer = blockIdx.y;
@@ -690,7 +782,16 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceArgs a) {
             const ReduceSeg g = a.seg[q];
             if (p >= g.p0 && p < g.p0 + g.len) {
                 const float *src = a.slabs + g.base + (p - g.p0);
-                for (int k = grp; k < g.rows; k += 8) s += src[(int64_t)k * g.row_stride];
+                // 8 independent row loads in flight; the summation order is fixed (deterministic)
+                int k = grp;
+                for (; k + 56 < g.rows; k += 64) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + 8 * u) * g.row_stride];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += v[u];
+                }
+                for (; k < g.rows; k += 8) s += src[(int64_t)k * g.row_stride];
             }
         }
     }
@@ -749,7 +850,7 @@ struct WgradGeom {
     size_t lds;
 };
 static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
-    const size_t per_wave = ((size_t)plane_slot(V) + ((Cfg::P * Cfg::C * V + 3) & ~3)) * sizeof(float);
+    const size_t per_wave = ((size_t)plane_slot(V) + dz_slot(V)) * sizeof(float);
     if (per_wave > (size_t)kLdsBytes) return false;
     int waves = env_waves("STG_WGRAD_WAVES", 4);
     while (waves > 1 && per_wave * waves > (size_t)kLdsBytes) waves >>= 1;
@@ -781,7 +882,12 @@ static int64_t bwd_scratch_floats(const ModelLayout &L, int N, int V) {
         if (!wgrad_geom(L, N, V, &g)) return -1;
         fl += wgrad_slab_base(L.L + 1, g.rows);
         fl = (fl + 3) & ~(int64_t)3;
-        fl += (int64_t)N * L.L * (Cfg::P * Cfg::C * V);
+        fl += (int64_t)N * L.L * dz_slot(V);
+        if (txp_wave_fits(L, V)) {
+            fl += (int64_t)N * (Cfg::C * Cfg::T * V);            // d(a_0) hand-off
+            fl = (fl + 3) & ~(int64_t)3;
+            fl += (int64_t)N * L.n_txp;                          // per-scene PReLU slope gradients
+        }
     }
     return fl;
 }
@@ -837,12 +943,31 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         off += wgrad_slab_base(L.L + 1, wg.rows);
         off = (off + 3) & ~(int64_t)3;
         dzg = scratch + off;
+        off += (int64_t)N * L.L * dz_slot(V);
+    }
+    const bool wave_path = txp_wave_fits(L, V);
+    float *da0 = nullptr, *slopes = nullptr;
+    if (wave_path) {
+        da0 = scratch + off;
+        off += (int64_t)N * (Cfg::C * Cfg::T * V);
+        off = (off + 3) & ~(int64_t)3;
+        slopes = scratch + off;
     }
     a.params = params; a.buffers = buffers; a.x = x;
     a.x_sn = x_sn; a.x_sc = x_sc; a.x_st = x_st; a.x_sv = x_sv;
     a.adj = adj; a.a_sn = a_sn; a.num_peds = num_peds; a.N = N; a.V = V;
     a.dy = dy; a.ws = ws; a.ws_stride = ws_floats_per_scene(L, V); a.slab1 = slab1; a.dzg = dzg; a.dx = dx;
     if (const char *e = getenv("STG_DEBUG_SKIP")) a.debug_skip = atoi(e);
+    if (wave_path) {
+        TxpBwdArgs t{};
+        t.lay = L; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V; t.dy = dy; t.ws = ws;
+        t.ws_stride = a.ws_stride; t.dzg = dzg; t.da0 = da0; t.slopes = slopes;
+        if (!(a.debug_skip & 2)) {
+            const int rcw = launch_txp_bwd_wave(t, st);
+            if (rcw != STG_OK) return rcw;
+        }
+        a.da0 = da0;
+    }
 #define STG_LAUNCH_BWD(W)                                                                                    \
     do {                                                                                                     \
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&model_bwd_kernel<W>),            \
@@ -865,10 +990,13 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     r.n_params = L.n_params;
     r.seg[r.n_seg++] = ReduceSeg{0, L.n_blk_params, grid, n_small, 0};
     if (L.n_txp > 0) {
-        r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, grid, n_small, (int64_t)L.n_blk_params};
+        if (wave_path)
+            r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, (a.debug_skip & 2) ? 0 : N, L.n_txp, (int64_t)(slopes - scratch)};
+        else
+            r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, grid, n_small, (int64_t)L.n_blk_params};
         WgradArgs w{};
         w.lay = L; w.num_peds = num_peds; w.N = N; w.V = V; w.dy = dy; w.ws = ws; w.dzg = dzg;
-        w.ws_stride = a.ws_stride; w.slab2 = slab2; w.rows = wg.rows;
+        w.ws_stride = a.ws_stride; w.slab2 = slab2; w.rows = wg.rows; w.debug_skip = a.debug_skip;
         if (!(a.debug_skip & 1)) {
             const dim3 g2(wg.grid_x, L.L + 1);
 #define STG_LAUNCH_WG(W)                                                                                     \

@@ -13,6 +13,7 @@
 //    B operand is one ds_read_b32 per MFMA from a zero-bordered LDS plane whose channel stride is
 //    == 16 (mod 32) dwords (conflict-free for the four K-lane groups).
 #include "model_common.hpp"
+#include "txp_wave.hpp"
 
 namespace stg {
 
@@ -27,6 +28,7 @@ struct FwdArgs {
     float *y, *ws;
     int64_t ws_stride;
     float *stats;
+    float *a0g;       // non-null: blocks only -- the a_0 plane goes to a0g[n] for the wave-per-scene TXP kernel
     int debug_skip;   // timing-only diagnostic (STG_DEBUG_SKIP): 16 TXP-CNN, 32 st_gcn -- wrong results
 };
 
@@ -430,19 +432,39 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a) 
             float *tmp = X; X = H; H = tmp;      // block output becomes the next block's input
         }
         if (L.n_txp == 0 || (a.debug_skip & 16)) continue;
+        if (a.a0g) {
+            // hand the zero-bordered channel-major a_0 plane to txp_fwd_wave_kernel (linear 16-byte copy) and,
+            // in training, save it position-major for the weight-gradient GEMM
+            float4 *dst = reinterpret_cast<float4 *>(a.a0g + (int64_t)n * plane_slot(V));
+            const float4 *src = reinterpret_cast<const float4 *>(bufA);
+            for (int e = tid; e < (P * SC) >> 2; e += NT) dst[e] = src[e];
+            if (wsn) {
+                float *d2 = wsn + ws_plane_off(L, V, 0);
+                const int npad = (C + 2) * SW;
+                for (int e = tid; e < npad * P; e += NT) {
+                    const int pos = e / P, ch = e - pos * P;
+                    d2[e] = bufA[ch * SC + pos];
+                }
+            }
+            continue;
+        }
         // ---- TXP-CNN (model.py:187-195) ------------------------------------------------------
         float *bufB = reg;
         for (int e = tid; e < P * SC; e += NT) bufB[e] = 0.f;
         __syncthreads();
         const float *Pm = a.params;
         float *in = bufA, *out = bufB;
-        // a_l leaves as a whole zero-bordered plane (linear 16-byte stores): the weight-gradient kernel
-        // stages it back into LDS with a linear copy
+        // a_l leaves as a whole zero-bordered plane, transposed to position-major [(C+2)*SW][P] with
+        // coalesced stores: the layout the weight-gradient GEMM (K = positions, 16 lanes = 16 channels/taps)
+        // stages back with a linear LDS-DMA copy and reads without bank conflicts
         auto save_plane = [&](const float *pl, int idx) {
             if (!wsn) return;
-            float4 *dst = reinterpret_cast<float4 *>(wsn + ws_plane_off(L, V, idx));
-            const float4 *src = reinterpret_cast<const float4 *>(pl);
-            for (int e = tid; e < (P * SC) >> 2; e += NT) dst[e] = src[e];
+            float *dst = wsn + ws_plane_off(L, V, idx);
+            const int npad = (C + 2) * SW;
+            for (int e = tid; e < npad * P; e += NT) {
+                const int pos = e / P, ch = e - pos * P;
+                dst[e] = pl[ch * SC + pos];
+            }
         };
         save_plane(in, 0);
         for (int l = 0; l < L.L; ++l) {
@@ -469,10 +491,18 @@ static size_t fwd_lds_bytes(int V, int waves) {
 
 }  // namespace stg
 
+extern "C" int64_t stg_model_fwd_scratch_floats(const stg_model_desc *d, int N, int V) {
+    stg::ModelLayout l;
+    const int rc = stg::make_layout(d, &l);
+    if (rc != STG_OK) return rc;
+    if (N < 0 || V <= 0) return stg::fail(STG_EINVAL, "stg_model_fwd_scratch_floats: N=%d V=%d", N, V);
+    return stg::txp_wave_fits(l, V) ? (int64_t)N * stg::plane_slot(V) : 0;
+}
+
 extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const float *buffers, const float *x,
                              int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj,
                              int64_t a_sn, const int32_t *num_peds, int N, int V, float *y, float *ws,
-                             float *stats, void *stream) {
+                             float *stats, float *scratch, void *stream) {
     using namespace stg;
     FwdArgs a{};
     const int rc = make_layout(d, &a.lay);
@@ -484,8 +514,13 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     a.x_sn = x_sn; a.x_sc = x_sc; a.x_st = x_st; a.x_sv = x_sv;
     a.adj = adj; a.a_sn = a_sn; a.num_peds = num_peds; a.N = N; a.V = V;
     a.y = y; a.ws = ws; a.ws_stride = ws_floats_per_scene(a.lay, V); a.stats = stats;
+    const bool wave_path = txp_wave_fits(a.lay, V);
+    STG_REQUIRE(!wave_path || scratch, STG_EINVAL, "stg_model_fwd: scratch (stg_model_fwd_scratch_floats) is null");
+    STG_REQUIRE(!ws || (reinterpret_cast<uintptr_t>(ws) & 15) == 0, STG_EINVAL, "stg_model_fwd: ws must be 16-byte aligned");
+    a.a0g = wave_path ? scratch : nullptr;
     if (const char *e = getenv("STG_DEBUG_SKIP")) a.debug_skip = atoi(e);
     int waves = V <= 12 ? 1 : (V <= 40 ? 2 : (V <= 80 ? 4 : 8));
+    if (wave_path) waves = V <= 4 ? 1 : (V <= 12 ? 2 : 4);     // blocks only: one lane per (t, w) column
     if (const char *e = getenv("STG_FWD_WAVES")) {
         const int w = atoi(e);
         if (w == 1 || w == 2 || w == 4 || w == 8) waves = w;
@@ -510,5 +545,11 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     }
 #undef STG_LAUNCH_FWD
     STG_LAUNCH_CHECK("stg_model_fwd");
+    if (wave_path && !(a.debug_skip & 16)) {
+        TxpFwdArgs t{};
+        t.lay = a.lay; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V;
+        t.a0g = scratch; t.y = y; t.ws = ws; t.ws_stride = a.ws_stride;
+        return launch_txp_fwd_wave(t, st);
+    }
     return STG_OK;
 }

@@ -1,0 +1,36 @@
+// Wave-per-scene TXP-CNN kernels (txp_wave.hip): argument blocks and launchers.
+#pragma once
+#include "model_common.hpp"
+
+namespace stg {
+
+struct TxpFwdArgs {
+    ModelLayout lay;
+    const float *params;
+    const int32_t *num_peds;
+    int N, V;
+    const float *a0g;      // [N][plane_slot(V)] channel-major zero-bordered a_0 planes from the block kernel
+    float *y;              // (N, C, P, V)
+    float *ws;             // per-scene workspace or null (inference)
+    int64_t ws_stride;
+};
+
+struct TxpBwdArgs {
+    ModelLayout lay;
+    const float *params;
+    const int32_t *num_peds;
+    int N, V;
+    const float *dy;       // (N, C, P, V)
+    const float *ws;
+    int64_t ws_stride;
+    float *dzg;            // [N][L][dz_slot(V)]   dz_l of the hidden layers for the weight-gradient GEMM
+    float *da0;            // [N][C*T*V]           gradient w.r.t. the st_gcn block output
+    float *slopes;         // [N][n_txp]           per-scene PReLU slope gradients
+};
+
+// true when the wave-per-scene path serves this model / V (else the workgroup-per-scene kernels run)
+bool txp_wave_fits(const ModelLayout &L, int V);
+int launch_txp_fwd_wave(const TxpFwdArgs &a, hipStream_t st);
+int launch_txp_bwd_wave(const TxpBwdArgs &a, hipStream_t st);
+
+}  // namespace stg

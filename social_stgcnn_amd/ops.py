@@ -222,12 +222,18 @@ class _FusedModel(torch.autograd.Function):
         if training:
             sf = L.stg_model_stat_floats(ctypes.byref(desc))
             stats = torch.empty((n, max(int(sf), 1)), device=x.device, dtype=torch.float32)
+        scr = None
+        nscr = L.stg_model_fwd_scratch_floats(ctypes.byref(desc), n, v)
+        if nscr < 0:
+            check(int(nscr), "stg_model_fwd_scratch_floats")
+        if nscr > 0:
+            scr = torch.empty(int(nscr), device=x.device, dtype=torch.float32)
         sn, sc, st, sv = x.stride()
         ev = TIMER.bracket("model_fwd") if TIMER is not None else None
         if ev:
             ev[0].record()
         check(L.stg_model_fwd(ctypes.byref(desc), ptr(flat_params), ptr(flat_buffers), ptr(x), sn, sc, st, sv,
-                              ptr(adj_c), a_sn, ptr(peds), n, v, ptr(y), ptr(ws), ptr(stats), stream_ptr()),
+                              ptr(adj_c), a_sn, ptr(peds), n, v, ptr(y), ptr(ws), ptr(stats), ptr(scr), stream_ptr()),
               "stg_model_fwd")
         if ev:
             ev[1].record()
