@@ -887,6 +887,7 @@ static int64_t bwd_scratch_floats(const ModelLayout &L, int N, int V) {
             fl += (int64_t)N * (Cfg::C * Cfg::T * V);            // d(a_0) hand-off
             fl = (fl + 3) & ~(int64_t)3;
             fl += (int64_t)N * L.n_txp;                          // per-scene PReLU slope gradients
+            fl = ((fl + 3) & ~(int64_t)3) + 4;                   // scene queue head
         }
     }
     return fl;
@@ -962,6 +963,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         TxpBwdArgs t{};
         t.lay = L; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V; t.dy = dy; t.ws = ws;
         t.ws_stride = a.ws_stride; t.dzg = dzg; t.da0 = da0; t.slopes = slopes;
+        t.counter = reinterpret_cast<int *>(scratch + (((slopes - scratch) + (int64_t)N * L.n_txp + 3) & ~(int64_t)3));
         if (!(a.debug_skip & 2)) {
             const int rcw = launch_txp_bwd_wave(t, st);
             if (rcw != STG_OK) return rcw;

@@ -496,7 +496,8 @@ extern "C" int64_t stg_model_fwd_scratch_floats(const stg_model_desc *d, int N, 
     const int rc = stg::make_layout(d, &l);
     if (rc != STG_OK) return rc;
     if (N < 0 || V <= 0) return stg::fail(STG_EINVAL, "stg_model_fwd_scratch_floats: N=%d V=%d", N, V);
-    return stg::txp_wave_fits(l, V) ? (int64_t)N * stg::plane_slot(V) : 0;
+    const bool stamps = getenv("STG_STAMPS") != nullptr;
+    return stg::txp_wave_fits(l, V) ? (int64_t)N * stg::plane_slot(V) + 4 + (stamps ? (int64_t)N * 32 : 0) : 0;
 }
 
 extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const float *buffers, const float *x,
@@ -549,6 +550,8 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         TxpFwdArgs t{};
         t.lay = a.lay; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V;
         t.a0g = scratch; t.y = y; t.ws = ws; t.ws_stride = a.ws_stride;
+        t.counter = reinterpret_cast<int *>(scratch + (int64_t)N * plane_slot(V));
+        t.stamps = getenv("STG_STAMPS") ? reinterpret_cast<unsigned long long *>(scratch + (int64_t)N * plane_slot(V) + 4) : nullptr;
         return launch_txp_fwd_wave(t, st);
     }
     return STG_OK;

@@ -43,40 +43,108 @@ __device__ __forceinline__ void load_w_bwd(const float *__restrict__ W, float (&
             wreg[tap * 3 + j] = ci < CINL ? W[((4 * j + kq) * CINL + ci) * 9 + (8 - tap)] : 0.f;
 }
 
-// one pair of 16-position tiles: acc[u][r] = sum_k wreg[k] * plane[base[u] + koff(k)]
-template <int KJ>
-__device__ __forceinline__ void tile_pair(const float (&wreg)[9 * KJ], const float *plane, const int (&base)[2],
-                                          int SW, int SC, f32x4 &acc0, f32x4 &acc1) {
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int toff = (tap / 3) * SW + (tap % 3);
-#pragma unroll
-        for (int j = 0; j < KJ; ++j) {
-            const float b0 = plane[base[0] + 4 * j * SC + toff];
-            const float b1 = plane[base[1] + 4 * j * SC + toff];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap * KJ + j], b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[tap * KJ + j], b1, acc1, 0, 0, 0);
-        }
+// ---- pipelined tile loop ------------------------------------------------------------------------
+// A scene's positions are walked in pairs of 16-position tiles.  Per pair: the im2col B operands of the
+// NEXT pair are fetched from LDS (all reads in flight) before the 18*KJ MFMAs of the CURRENT pair issue,
+// and the epilogue of the PREVIOUS pair sits in the same basic block as those MFMAs, so the scheduler
+// slots its VALU / LDS / store instructions into the matrix pipe's issue gaps.
+struct TileGeom {
+    int hh[2], ww[2], pos[2];
+    bool ok[2];
+};
+
+// position -> (h << 16 | w) table of the scene (one LDS word per position; no integer divisions per tile)
+__device__ __forceinline__ void build_ptab(unsigned *ptab, int vi, int npos) {
+    const int lane = threadIdx.x & 63;
+    for (int p = lane; p < npos; p += 64) {
+        const int h = p / vi;
+        ptab[p] = ((unsigned)h << 16) | (unsigned)(p - h * vi);
     }
 }
 
-struct TileGeom {
-    int hh[2], ww[2], base[2], pos[2];
-    bool ok[2];
-};
-__device__ __forceinline__ TileGeom tile_geom(int tile0, int vi, int npos, int SW, int SC) {
-    const int lane = threadIdx.x & 63, nq = lane & 15, kq = lane >> 4;
+__device__ __forceinline__ TileGeom tile_geom(int tile0, const unsigned *ptab, int npos) {
+    const int nq = threadIdx.x & 15;
     TileGeom g;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int p = (tile0 + u) * 16 + nq;
         g.ok[u] = p < npos;
         g.pos[u] = g.ok[u] ? p : 0;
-        g.hh[u] = g.pos[u] / vi;
-        g.ww[u] = g.pos[u] - g.hh[u] * vi;
-        g.base[u] = kq * SC + g.hh[u] * SW + g.ww[u];
+        const unsigned hw = ptab[g.pos[u]];
+        g.hh[u] = (int)(hw >> 16);
+        g.ww[u] = (int)(hw & 0xffffu);
     }
     return g;
+}
+
+template <int KJ>
+struct BRegs {
+    float v[2][9 * KJ];
+};
+
+template <int KJ>
+__device__ __forceinline__ void load_b(const float *__restrict__ plane, const TileGeom &g, int SW, int SC,
+                                       BRegs<KJ> &b) {
+    const int kq = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float *q0 = plane + kq * SC + g.hh[u] * SW + g.ww[u];
+#pragma unroll
+        for (int j = 0; j < KJ; ++j)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float *q = q0 + 4 * j * SC + kh * SW;      // kw = 0,1,2 become immediate offsets
+                b.v[u][(kh * 3 + 0) * KJ + j] = q[0];
+                b.v[u][(kh * 3 + 1) * KJ + j] = q[1];
+                b.v[u][(kh * 3 + 2) * KJ + j] = q[2];
+            }
+    }
+}
+
+template <int KJ>
+__device__ __forceinline__ void mma_pair(const float (&wreg)[9 * KJ], const BRegs<KJ> &b, f32x4 &acc0, f32x4 &acc1) {
+#pragma unroll
+    for (int k = 0; k < 9 * KJ; ++k) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[k], b.v[0][k], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[k], b.v[1][k], acc1, 0, 0, 0);
+    }
+}
+
+// epi(geom, u, acc) finishes tile u of a pair
+template <int KJ, typename Epi>
+__device__ __forceinline__ void conv_tiles(const float (&wreg)[9 * KJ], const f32x4 binit,
+                                           const float *__restrict__ plane, const unsigned *ptab, int npos, int SW,
+                                           int SC, Epi epi) {
+    const int ntiles = (npos + 15) >> 4;
+    TileGeom g_cur = tile_geom(0, ptab, npos), g_prev = g_cur;
+    BRegs<KJ> b_cur;
+    load_b<KJ>(plane, g_cur, SW, SC, b_cur);
+    f32x4 p0 = binit, p1 = binit;
+    bool have_prev = false;
+    for (int tile0 = 0; tile0 < ntiles; tile0 += 2) {
+        const bool has_next = tile0 + 2 < ntiles;
+        TileGeom g_nxt = g_cur;
+        BRegs<KJ> b_nxt = b_cur;
+        if (has_next) {
+            g_nxt = tile_geom(tile0 + 2, ptab, npos);
+            load_b<KJ>(plane, g_nxt, SW, SC, b_nxt);
+        }
+        f32x4 c0 = binit, c1 = binit;
+        mma_pair<KJ>(wreg, b_cur, c0, c1);
+        if (have_prev) {
+            epi(g_prev, 0, p0);
+            epi(g_prev, 1, p1);
+        }
+        p0 = c0; p1 = c1;
+        g_prev = g_cur;
+        have_prev = true;
+        g_cur = g_nxt;
+        b_cur = b_nxt;
+    }
+    if (have_prev) {
+        epi(g_prev, 0, p0);
+        epi(g_prev, 1, p1);
+    }
 }
 
 // zero a wave-private plane (borders must be 0; interiors are rewritten every layer)
@@ -103,43 +171,36 @@ __device__ __forceinline__ void wave_dma(const float *__restrict__ src, float *l
 // KIND 0: layer 0 (PReLU), 1: hidden layer with residual, 2: output conv (writes y)
 template <int CINL, int KIND>
 __device__ __forceinline__ void fwd_layer(const float (&wreg)[CINL * 9 / 4], const float *__restrict__ bias, float alpha,
-                                          const float *in, float *out, int vi, int V, float *zsave, float *psave,
-                                          float *yout) {
-    const int lane = threadIdx.x & 63, kq = lane >> 4;
-    const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi, ntiles = (npos + 15) >> 4;
+                                          const float *__restrict__ in, float *__restrict__ out, const unsigned *ptab,
+                                          int vi, int V, float *zsave, float *psave, float *yout) {
+    const int kq = (threadIdx.x & 63) >> 4;
+    const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi;
     f32x4 binit;
 #pragma unroll
     for (int r = 0; r < 4; ++r) binit[r] = kq < 3 ? bias[4 * kq + r] : 0.f;
-    for (int tile0 = 0; tile0 < ntiles; tile0 += 2) {
-        const TileGeom g = tile_geom(tile0, vi, npos, SW, SC);
-        f32x4 acc0 = binit, acc1 = binit;
-        tile_pair<CINL / 4>(wreg, in, g.base, SW, SC, acc0, acc1);
+    conv_tiles<CINL / 4>(wreg, binit, in, ptab, npos, SW, SC, [&](const TileGeom &g, int u, const f32x4 &z) {
+        if (!g.ok[u] || kq == 3) return;
+        if (KIND == 2) {
+            // v.view(N, C, P, V) (model.py:195): the (P, C, V) conv output IS the (C, P, V) tensor
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (!g.ok[u] || kq == 3) continue;
-            const f32x4 z = u == 0 ? acc0 : acc1;
-            if (KIND == 2) {
-                // v.view(N, C, P, V) (model.py:195): the (P, C, V) conv output IS the (C, P, V) tensor
+            for (int r = 0; r < 4; ++r) yout[(int64_t)((4 * kq + r) * C + g.hh[u]) * V + g.ww[u]] = z[r];
+        } else {
+            const int pp = (g.hh[u] + 1) * SW + (g.ww[u] + 1);
+            f32x4 av;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) yout[(int64_t)((4 * kq + r) * C + g.hh[u]) * V + g.ww[u]] = z[r];
-            } else {
-                const int pp = (g.hh[u] + 1) * SW + (g.ww[u] + 1);
-                f32x4 av;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int li = (4 * kq + r) * SC + pp;
-                    float v = z[r] > 0.f ? z[r] : alpha * z[r];
-                    if (KIND == 1) v += in[li];
-                    out[li] = v;
-                    av[r] = v;
-                }
-                if (zsave) {   // position-major [pos][12]: one 16-byte store per lane
-                    *reinterpret_cast<f32x4 *>(zsave + g.pos[u] * P + 4 * kq) = z;
-                    *reinterpret_cast<f32x4 *>(psave + pp * P + 4 * kq) = av;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int li = (4 * kq + r) * SC + pp;
+                float v = z[r] > 0.f ? z[r] : alpha * z[r];
+                if (KIND == 1) v += in[li];
+                out[li] = v;
+                av[r] = v;
+            }
+            if (zsave) {   // position-major [pos][12]: one 16-byte store per lane
+                *reinterpret_cast<f32x4 *>(zsave + g.pos[u] * P + 4 * kq) = z;
+                *reinterpret_cast<f32x4 *>(psave + pp * P + 4 * kq) = av;
             }
         }
-    }
+    });
 }
 
 // zero the border positions of a saved position-major plane [(C+2)*SW][P] (interiors come from the epilogue)
@@ -159,15 +220,25 @@ __device__ __forceinline__ void zero_saved_borders(float *psave, int vi) {
     }
 }
 
-template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void txp_fwd_wave_kernel(const TxpFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+// next scene of the launch: waves pull scene indices from one device-scope counter (zeroed by a memset
+// node ahead of the launch), so every wave stays busy until the batch is drained -- no tail round
+__device__ __forceinline__ int next_scene(int *counter) {
+    int n = 0;
+    if ((threadIdx.x & 63) == 0) n = atomicAdd(counter, 1);
+    return __builtin_amdgcn_readfirstlane(n);
+}
+
+// diagnostic stamps (never read by the kernel; only with STG_STAMPS=1)
+#define STG_STAMP(k)                                                                         \
+    do {                                                                                     \
+        if (a.stamps && (threadIdx.x & 63) == 0) a.stamps[(int64_t)n * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+__device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float *pa, float *pb, unsigned *ptab) {
     const ModelLayout &L = a.lay;
-    const int V = a.V, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int V = a.V, lane = threadIdx.x & 63;
     const int slot = plane_slot(V);
-    float *pa = sm + wave * 2 * slot, *pb = pa + slot;
-    const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-    if (n >= a.N) return;
+    STG_STAMP(0);
     int vi = a.num_peds ? a.num_peds[n] : V;
     vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
     if (vi == 0) return;                               // (the block kernel already zero-filled y)
@@ -178,10 +249,12 @@ __global__ __launch_bounds__(WPB * 64) void txp_fwd_wave_kernel(const TxpFwdArgs
 
     wave_dma(a.a0g + (int64_t)n * slot, pa, (P * SC) >> 2);
     wave_zero(pb, (P * SC) >> 2);
+    build_ptab(ptab, vi, C * vi);
     float w0[T * 9 / 4];
     load_w_fwd<T>(Pm + L.txp_w[0], w0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    STG_STAMP(1);
 
     float *in = pa, *out = pb;
     float wa[27], wb[27];          // two weight register sets: layer l computes from one while l+1 loads
@@ -196,9 +269,10 @@ __global__ __launch_bounds__(WPB * 64) void txp_fwd_wave_kernel(const TxpFwdArgs
     load_w_fwd<P>(w_of(1), wa);
     {
         float *zs = zs_of(0), *ps = ps_of(0);
-        fwd_layer<T, 0>(w0, Pm + L.txp_b[0], Pm[L.prelus], in, out, vi, V, zs, ps, nullptr);
+        fwd_layer<T, 0>(w0, Pm + L.txp_b[0], Pm[L.prelus], in, out, ptab, vi, V, zs, ps, nullptr);
         float *t = in; in = out; out = t;
     }
+    STG_STAMP(2);
     int l = 1;
     bool in_a = true;              // which register set holds layer l's weights
     for (; l < L.L; ++l) {
@@ -206,59 +280,63 @@ __global__ __launch_bounds__(WPB * 64) void txp_fwd_wave_kernel(const TxpFwdArgs
         __builtin_amdgcn_wave_barrier();
         if (in_a) {
             load_w_fwd<P>(w_of(l + 1), wb);
-            fwd_layer<P, 1>(wa, Pm + L.txp_b[l], Pm[L.prelus + l], in, out, vi, V, zs, ps, nullptr);
+            fwd_layer<P, 1>(wa, Pm + L.txp_b[l], Pm[L.prelus + l], in, out, ptab, vi, V, zs, ps, nullptr);
         } else {
             load_w_fwd<P>(w_of(l + 1), wa);
-            fwd_layer<P, 1>(wb, Pm + L.txp_b[l], Pm[L.prelus + l], in, out, vi, V, zs, ps, nullptr);
+            fwd_layer<P, 1>(wb, Pm + L.txp_b[l], Pm[L.prelus + l], in, out, ptab, vi, V, zs, ps, nullptr);
         }
         in_a = !in_a;
         float *t = in; in = out; out = t;
+        STG_STAMP(2 + l);
     }
     __builtin_amdgcn_wave_barrier();
     if (in_a)
-        fwd_layer<P, 2>(wa, Pm + L.out_b, 0.f, in, out, vi, V, nullptr, nullptr, yn);
+        fwd_layer<P, 2>(wa, Pm + L.out_b, 0.f, in, out, ptab, vi, V, nullptr, nullptr, yn);
     else
-        fwd_layer<P, 2>(wb, Pm + L.out_b, 0.f, in, out, vi, V, nullptr, nullptr, yn);
+        fwd_layer<P, 2>(wb, Pm + L.out_b, 0.f, in, out, ptab, vi, V, nullptr, nullptr, yn);
+    STG_STAMP(8);
     (void)lane;
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64, 2) void txp_fwd_wave_kernel(const TxpFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int V = a.V, wave = threadIdx.x >> 6;
+    const int slot = plane_slot(V);
+    const int per_wave = 2 * slot + ((C * V + 3) & ~3);
+    float *pa = sm + wave * per_wave, *pb = pa + slot;
+    unsigned *ptab = reinterpret_cast<unsigned *>(pb + slot);
+    for (int n = next_scene(a.counter); n < a.N; n = next_scene(a.counter)) {
+        txp_fwd_scene(a, n, pa, pb, ptab);
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // backward: input-gradient chain
 // ------------------------------------------------------------------------------------------
 template <int CINL>
-__device__ __forceinline__ void dgrad_layer(const float (&wreg)[27], const float *dzb, float *dcur, int vi,
-                                            bool accumulate) {
-    const int lane = threadIdx.x & 63, kq = lane >> 4;
-    const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi, ntiles = (npos + 15) >> 4;
-    for (int tile0 = 0; tile0 < ntiles; tile0 += 2) {
-        const TileGeom g = tile_geom(tile0, vi, npos, SW, SC);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        tile_pair<3>(wreg, dzb, g.base, SW, SC, acc0, acc1);
+__device__ __forceinline__ void dgrad_layer(const float (&wreg)[27], const float *__restrict__ dzb,
+                                            float *__restrict__ dcur, const unsigned *ptab, int vi, bool accumulate) {
+    const int kq = (threadIdx.x & 63) >> 4;
+    const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    conv_tiles<3>(wreg, zero, dzb, ptab, npos, SW, SC, [&](const TileGeom &g, int u, const f32x4 &acc) {
+        if (!g.ok[u]) return;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (!g.ok[u]) continue;
-            const f32x4 acc = u == 0 ? acc0 : acc1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ci = 4 * kq + r;
-                if (ci < CINL) {
-                    const int i = ci * npos + g.pos[u];
-                    dcur[i] = accumulate ? dcur[i] + acc[r] : acc[r];
-                }
+        for (int r = 0; r < 4; ++r) {
+            const int ci = 4 * kq + r;
+            if (ci < CINL) {
+                const int i = ci * npos + g.pos[u];
+                dcur[i] = accumulate ? dcur[i] + acc[r] : acc[r];
             }
         }
-    }
+    });
 }
 
-template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void txp_bwd_wave_kernel(const TxpBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float *dzb, float *dcur, unsigned *ptab) {
     const ModelLayout &L = a.lay;
-    const int V = a.V, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = plane_slot(V);
-    float *dzb = sm + wave * (slot + P * C * V), *dcur = dzb + slot;
-    const int n = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-    if (n >= a.N) return;
+    const int V = a.V, lane = threadIdx.x & 63;
     int vi = a.num_peds ? a.num_peds[n] : V;
     vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
     float *slope_row = a.slopes + (int64_t)n * L.n_txp;
@@ -271,6 +349,7 @@ __global__ __launch_bounds__(WPB * 64) void txp_bwd_wave_kernel(const TxpBwdArgs
     const float *wsn = a.ws + n * a.ws_stride;
     const float *dyn = a.dy + (int64_t)n * (C * P) * V;
     wave_zero(dzb, (P * SC) >> 2);
+    build_ptab(ptab, vi, npos);
     float wr[27];
     load_w_bwd<P>(Pm + L.out_w, wr);
     __builtin_amdgcn_wave_barrier();
@@ -300,26 +379,37 @@ __global__ __launch_bounds__(WPB * 64) void txp_bwd_wave_kernel(const TxpBwdArgs
             const float *zl = wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V;
             float *dzo = a.dzg + ((int64_t)n * L.L + l) * dz_slot(V);
             const float alpha = Pm[L.prelus + l];
-            for (int e0 = lane; e0 < P * npos; e0 += 64 * U) {
-                float zv[U];
+            // z_l is position-major [pos][12]: 3 x 16 bytes per position; 8 vectors in flight per lane so the
+            // HBM latency is paid once per layer, not once per element batch
+            constexpr int UV = 8;
+            const int nvec = (P * npos) >> 2;                       // P*npos is a multiple of 4
+            const f32x4 *zl4 = reinterpret_cast<const f32x4 *>(zl);
+            for (int v0 = lane; v0 < nvec; v0 += 64 * UV) {
+                f32x4 zv[UV];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = e0 + 64 * u;
-                    zv[u] = e < P * npos ? zl[e] : 1.f;            // e = pos*12 + ch (contiguous read)
+                for (int u = 0; u < UV; ++u) {
+                    const int vv = v0 + 64 * u;
+                    zv[u] = vv < nvec ? zl4[vv] : f32x4{1.f, 1.f, 1.f, 1.f};
                 }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = e0 + 64 * u;
-                    if (e < P * npos) {
-                        const int p = e / P, ch = e - p * P, h = p / vi, w = p - h * vi;
-                        const float z = zv[u], d = dcur[ch * npos + p];
-                        float dz = d;
-                        if (!(z > 0.f)) {
-                            dz = alpha * d;
-                            slope_acc = fmaf(d, z, slope_acc);
+                for (int u = 0; u < UV; ++u) {
+                    const int vv = v0 + 64 * u;
+                    if (vv < nvec) {
+                        const int p = vv / 3, q = vv - p * 3;       // position, channel quad
+                        const unsigned hw = ptab[p];
+                        const int h = (int)(hw >> 16), w = (int)(hw & 0xffffu);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ch = 4 * q + r;
+                            const float z = zv[u][r], d = dcur[ch * npos + p];
+                            float dz = d;
+                            if (!(z > 0.f)) {
+                                dz = alpha * d;
+                                slope_acc = fmaf(d, z, slope_acc);
+                            }
+                            dzb[ch * SC + (h + 1) * SW + (w + 1)] = dz;
+                            dzo[ch * ld + p] = dz;
                         }
-                        dzb[ch * SC + (h + 1) * SW + (w + 1)] = dz;
-                        dzo[ch * ld + p] = dz;
                     }
                 }
             }
@@ -330,9 +420,9 @@ __global__ __launch_bounds__(WPB * 64) void txp_bwd_wave_kernel(const TxpBwdArgs
         if (l == 0) {
             float w8[27];
             load_w_bwd<T>(Pm + L.txp_w[0], w8);
-            dgrad_layer<T>(w8, dzb, dcur, vi, false);
+            dgrad_layer<T>(w8, dzb, dcur, ptab, vi, false);
         } else {
-            dgrad_layer<P>(wr, dzb, dcur, vi, !is_out);
+            dgrad_layer<P>(wr, dzb, dcur, ptab, vi, !is_out);
             if (l > 1) load_w_bwd<P>(Pm + L.txp_w[l - 1], wr);
         }
         __builtin_amdgcn_wave_barrier();
@@ -341,6 +431,20 @@ __global__ __launch_bounds__(WPB * 64) void txp_bwd_wave_kernel(const TxpBwdArgs
     for (int e = L.L + lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;
     float *dout = a.da0 + (int64_t)n * (C * T * V);
     for (int e = lane; e < C * T * vi; e += 64) dout[e] = dcur[e];
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64, 2) void txp_bwd_wave_kernel(const TxpBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int V = a.V, wave = threadIdx.x >> 6;
+    const int slot = plane_slot(V);
+    const int per_wave = slot + P * C * V + ((C * V + 3) & ~3);
+    float *dzb = sm + wave * per_wave, *dcur = dzb + slot;
+    unsigned *ptab = reinterpret_cast<unsigned *>(dcur + P * C * V);
+    for (int n = next_scene(a.counter); n < a.N; n = next_scene(a.counter)) {
+        txp_bwd_scene(a, n, dzb, dcur, ptab);
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 }  // namespace
@@ -358,6 +462,16 @@ static int wave_wpb(size_t per_wave) {
     return wpb;
 }
 
+// persistent grid: as many workgroups as the chip holds at once (LDS-limited, 2 waves per SIMD)
+static int wave_grid(size_t lds, int wpb, int N) {
+    int per_cu = (int)(kLdsBytes / lds);
+    if (per_cu * wpb > 8) per_cu = 8 / wpb;
+    if (per_cu < 1) per_cu = 1;
+    const int need = (N + wpb - 1) / wpb;
+    const int g = kNumCU * per_cu;
+    return g < need ? g : need;
+}
+
 bool txp_wave_fits(const ModelLayout &L, int V) {
     if (L.n_txp < 1 || L.n_blocks != 1) return false;
     if (const char *e = getenv("STG_NO_WAVE_PATH"))
@@ -367,10 +481,14 @@ bool txp_wave_fits(const ModelLayout &L, int V) {
 }
 
 int launch_txp_fwd_wave(const TxpFwdArgs &a, hipStream_t st) {
-    const size_t per_wave = (size_t)2 * plane_slot(a.V) * sizeof(float);
+    const size_t per_wave = ((size_t)2 * plane_slot(a.V) + ((C * a.V + 3) & ~3)) * sizeof(float);
     const int wpb = wave_wpb(per_wave);
     const size_t lds = per_wave * wpb;
-    const dim3 grid((a.N + wpb - 1) / wpb);
+    const dim3 grid(wave_grid(lds, wpb, a.N));
+    {
+        hipError_t e0 = hipMemsetAsync(a.counter, 0, 16, st);
+        if (e0 != hipSuccess) return hip_fail(e0, "txp_fwd_wave: counter memset");
+    }
 #define STG_L(W)                                                                                              \
     do {                                                                                                      \
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_fwd_wave_kernel<W>),          \
@@ -385,10 +503,14 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a, hipStream_t st) {
 }
 
 int launch_txp_bwd_wave(const TxpBwdArgs &a, hipStream_t st) {
-    const size_t per_wave = ((size_t)plane_slot(a.V) + (size_t)P * C * a.V) * sizeof(float);
+    const size_t per_wave = ((size_t)plane_slot(a.V) + (size_t)P * C * a.V + ((C * a.V + 3) & ~3)) * sizeof(float);
     const int wpb = wave_wpb(per_wave);
     const size_t lds = per_wave * wpb;
-    const dim3 grid((a.N + wpb - 1) / wpb);
+    const dim3 grid(wave_grid(lds, wpb, a.N));
+    {
+        hipError_t e0 = hipMemsetAsync(a.counter, 0, 16, st);
+        if (e0 != hipSuccess) return hip_fail(e0, "txp_bwd_wave: counter memset");
+    }
 #define STG_L(W)                                                                                              \
     do {                                                                                                      \
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_bwd_wave_kernel<W>),          \

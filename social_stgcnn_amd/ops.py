@@ -191,6 +191,7 @@ class KernelTimer:
 
 
 TIMER = None
+LAST_FWD_SCRATCH = None
 
 
 class _FusedModel(torch.autograd.Function):
@@ -228,6 +229,8 @@ class _FusedModel(torch.autograd.Function):
             check(int(nscr), "stg_model_fwd_scratch_floats")
         if nscr > 0:
             scr = torch.empty(int(nscr), device=x.device, dtype=torch.float32)
+            global LAST_FWD_SCRATCH
+            LAST_FWD_SCRATCH = scr          # diagnostics only (STG_STAMPS=1 reads the stamp tail)
         sn, sc, st, sv = x.stride()
         ev = TIMER.bracket("model_fwd") if TIMER is not None else None
         if ev:

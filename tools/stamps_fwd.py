@@ -1,0 +1,33 @@
+"""Diagnostic (STG_STAMPS=1): per-phase wave timelines of txp_fwd_wave_kernel."""
+import os, sys
+os.environ["STG_STAMPS"] = "1"
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import bench
+from social_stgcnn_amd import ops
+from social_stgcnn_amd.model import social_stgcnn
+dev = torch.device("cuda", 0)
+n, v = 2048, 32
+obs_rel, target = bench.synth_scenes(n, v, 1)
+nodes, adj = ops.adj_build(torch.from_numpy(obs_rel).to(dev))
+x = nodes.permute(0, 3, 1, 2)
+torch.manual_seed(0)
+m = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3, pred_seq_len=12).to(dev).train()
+for _ in range(3): m(x, adj)
+torch.cuda.synchronize()
+scr = ops.LAST_FWD_SCRATCH
+slot = 12 * 240
+st = scr[n * slot + 4: n * slot + 4 + n * 32].cpu().numpy().view(np.uint64).reshape(n, 16).astype(np.int64)
+t0 = st[:, 0].min()
+print("kernel span (cycles): %d   scenes: %d" % (st[:, 8].max() - t0, n))
+d = np.diff(st[:, :9], axis=1)
+names = ["dma+w0 wait", "layer0", "layer1", "layer2", "layer3", "(unused)", "(unused)", "out layer"]
+for k in range(8):
+    if k in (5, 6): continue
+    col = d[:, k] if k < 5 else None
+names2 = ["stage/wait", "layer0", "layer1", "layer2", "layer3", "out"]
+seg = np.stack([st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2], st[:, 4] - st[:, 3], st[:, 5] - st[:, 4], st[:, 8] - st[:, 5]], 1)
+for k, nm in enumerate(names2):
+    print("%-12s median %7d  p10 %7d  p90 %7d cycles" % (nm, np.median(seg[:, k]), np.percentile(seg[:, k], 10), np.percentile(seg[:, k], 90)))
+life = st[:, 8] - st[:, 0]
+print("scene total  median %d cycles; start spread: p50 %d p90 %d max %d" % (np.median(life), np.percentile(st[:, 0] - t0, 50), np.percentile(st[:, 0] - t0, 90), (st[:, 0] - t0).max()))
