@@ -125,6 +125,46 @@ class Trainer:
         ops.sgd_step(flat_p, flat_g, self.lr)
         return total, losses, y
 
+    # ---- hipGraph capture of the step (launch-bound at these sizes: ~15 kernels of 10-150 us) ----------
+    def capture(self, x, adj, target, num_peds=None, weights=None, warmup=3):
+        """Capture forward + loss + backward (+ SGD update when single-rank) into ONE hipGraph on static
+        input tensors and return `replay()`.  x / adj / target / num_peds / weights must be device tensors
+        that stay alive; refresh their contents in place between replays.  With several ranks the graph
+        holds forward+backward and the gradient all-reduce, BatchNorm fold and SGD run eagerly after it."""
+        if num_peds is not None and not (torch.is_tensor(num_peds) and num_peds.is_cuda):
+            raise ValueError("capture() needs num_peds as a device tensor (no host->device copies in a graph)")
+        single = self.world == 1
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                if single:
+                    self.step(x, adj, target, num_peds, weights)
+                else:
+                    self.forward_backward(x, adj, target, num_peds, weights)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.step(x, adj, target, num_peds, weights) if single else \
+                self.forward_backward(x, adj, target, num_peds, weights)
+        model = self.model
+
+        def replay():
+            if single:
+                graph.replay()
+                return out
+            before = model._pb.flat.clone()
+            graph.replay()
+            flat_g = self._flat_grad()
+            allreduce_flat(flat_g, self.group)
+            n_local = int(x.shape[0])
+            mom = model.st_gcns[0].tcn[0].momentum
+            model._pb.flat.copy_(fold_bn_across_ranks(before, model._pb.flat, n_local, mom, self.group))
+            ops.sgd_step(model.flat_parameters(), flat_g, self.lr)
+            return out
+        self._graph = graph
+        return replay
+
     def _flat_grad(self):
         """Gradients as one flat buffer in parameter order (dead parameters contribute zeros)."""
         flat = getattr(self.model, "_flat_grad", None)
