@@ -826,7 +826,9 @@ static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves) {
     return fl * sizeof(float);
 }
 
-static int bwd_waves(int V) { return env_waves("STG_BWD_WAVES", V <= 12 ? 1 : (V <= 40 ? 2 : (V <= 80 ? 4 : 8))); }
+// measured (profiles/): the st_gcn backward is fastest with ONE wave per scene up to V ~ 40 (no cross-wave
+// barriers in its ~15 block reductions), more waves only when a scene's rows no longer fit one wave's registers
+static int bwd_waves(int V) { return env_waves("STG_BWD_WAVES", V <= 40 ? 1 : (V <= 80 ? 4 : 8)); }
 
 static int bwd_grid(const ModelLayout &L, int N, int V) {
     const int waves = bwd_waves(V);

@@ -43,11 +43,9 @@ __device__ __forceinline__ void load_w_bwd(const float *__restrict__ W, float (&
             wreg[tap * 3 + j] = ci < CINL ? W[((4 * j + kq) * CINL + ci) * 9 + (8 - tap)] : 0.f;
 }
 
-// ---- pipelined tile loop ------------------------------------------------------------------------
-// A scene's positions are walked in pairs of 16-position tiles.  Per pair: the im2col B operands of the
-// NEXT pair are fetched from LDS (all reads in flight) before the 18*KJ MFMAs of the CURRENT pair issue,
-// and the epilogue of the PREVIOUS pair sits in the same basic block as those MFMAs, so the scheduler
-// slots its VALU / LDS / store instructions into the matrix pipe's issue gaps.
+// ---- tile loop ------------------------------------------------------------------------------------
+// A scene's positions are walked in pairs of 16-position tiles: all 18*KJ im2col reads of the pair are
+// issued (kw offsets as ds_read immediates), then the 18*KJ MFMAs on two independent accumulators.
 struct TileGeom {
     int hh[2], ww[2], pos[2];
     bool ok[2];
@@ -110,40 +108,21 @@ __device__ __forceinline__ void mma_pair(const float (&wreg)[9 * KJ], const BReg
     }
 }
 
-// epi(geom, u, acc) finishes tile u of a pair
+// epi(geom, u, acc) finishes tile u of a pair.  (A software-pipelined form -- next pair's operands fetched
+// ahead, previous pair's epilogue deferred -- measured no faster and cost 100 VGPRs: tools/micro/conv_tile_bench.)
 template <int KJ, typename Epi>
 __device__ __forceinline__ void conv_tiles(const float (&wreg)[9 * KJ], const f32x4 binit,
                                            const float *__restrict__ plane, const unsigned *ptab, int npos, int SW,
                                            int SC, Epi epi) {
     const int ntiles = (npos + 15) >> 4;
-    TileGeom g_cur = tile_geom(0, ptab, npos), g_prev = g_cur;
-    BRegs<KJ> b_cur;
-    load_b<KJ>(plane, g_cur, SW, SC, b_cur);
-    f32x4 p0 = binit, p1 = binit;
-    bool have_prev = false;
     for (int tile0 = 0; tile0 < ntiles; tile0 += 2) {
-        const bool has_next = tile0 + 2 < ntiles;
-        TileGeom g_nxt = g_cur;
-        BRegs<KJ> b_nxt = b_cur;
-        if (has_next) {
-            g_nxt = tile_geom(tile0 + 2, ptab, npos);
-            load_b<KJ>(plane, g_nxt, SW, SC, b_nxt);
-        }
+        const TileGeom g = tile_geom(tile0, ptab, npos);
+        BRegs<KJ> b;
+        load_b<KJ>(plane, g, SW, SC, b);
         f32x4 c0 = binit, c1 = binit;
-        mma_pair<KJ>(wreg, b_cur, c0, c1);
-        if (have_prev) {
-            epi(g_prev, 0, p0);
-            epi(g_prev, 1, p1);
-        }
-        p0 = c0; p1 = c1;
-        g_prev = g_cur;
-        have_prev = true;
-        g_cur = g_nxt;
-        b_cur = b_nxt;
-    }
-    if (have_prev) {
-        epi(g_prev, 0, p0);
-        epi(g_prev, 1, p1);
+        mma_pair<KJ>(wreg, b, c0, c1);
+        epi(g, 0, c0);
+        epi(g, 1, c1);
     }
 }
 
