@@ -49,6 +49,8 @@ struct WgradArgs {
     int64_t ws_stride;
     float *slab2;          // [layer 0..L][rows][row_len(layer)] packed, see wgrad_slab_base()
     int rows;              // slab rows per layer = gridDim.x * WAVES
+    int *counters;         // [L+1] scene queue heads, one per layer (zeroed by the launcher)
+    int wg_begin[kMaxTxp + 2];   // workgroup ranges per layer: layer l owns blocks [wg_begin[l], wg_begin[l+1])
     int debug_skip;        // timing-only diagnostic: 64 skip staging, 128 skip the MFMA loop
 };
 
@@ -602,16 +604,57 @@ __device__ __forceinline__ void wave_dma_copy(const float *__restrict__ src, flo
     }
 }
 
+// stage scene n of `layer` into one wave-private LDS image: a_l (zero-bordered, position-major
+// [(C+2)*SW][P]) and dz_l ([P][ld]); LDS-DMA where the source is linear (caller waits vmcnt(0))
 template <int CINL>
-__device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float *plane, float *dzs, int gwave,
-                                            int nwaves) {
+__device__ __forceinline__ void wgrad_stage(const WgradArgs &a, int layer, int n, int vi, float *plane, float *dzs) {
+    constexpr int C = Cfg::C, P = Cfg::P;
+    const ModelLayout &L = a.lay;
+    const int V = a.V, lane = threadIdx.x & 63;
+    const int SW = txp_sw(vi), npos = C * vi, ld = dz_stride(vi);
+    const float *wsn = a.ws + n * a.ws_stride;
+    wave_dma_copy(wsn + ws_plane_off(L, V, layer), plane, ((C + 2) * SW * P + 3) >> 2);
+    if (layer == L.L) {
+        // the output conv's dz is dy itself: (C*P) rows of V floats, vi valid -> [P][ld]
+        const float *dyn = a.dy + (int64_t)n * (C * P) * V;
+        constexpr int U = 8;
+        for (int e0 = lane; e0 < P * npos; e0 += 64 * U) {
+            float dv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + 64 * u;
+                const int ec = e < P * npos ? e : 0;
+                const int row = ec / vi, w = ec - row * vi;        // row = co*C + h
+                dv[u] = dyn[(int64_t)row * V + w];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + 64 * u;
+                if (e < P * npos) {
+                    const int co = e / npos;
+                    dzs[co * ld + (e - co * npos)] = dv[u];
+                }
+            }
+        }
+    } else {
+        wave_dma_copy(a.dzg + ((int64_t)n * L.L + layer) * dz_slot(V), dzs, (P * ld + 3) >> 2);
+    }
+}
+
+__device__ __forceinline__ int wgrad_vi(const WgradArgs &a, int n) {
+    int vi = a.num_peds ? a.num_peds[n] : a.V;
+    return __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > a.V ? a.V : vi));
+}
+
+template <int CINL>
+__device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float *buf0, float *buf1, int row_id,
+                                            int nrows) {
     constexpr int C = Cfg::C, P = Cfg::P;
     constexpr int NCOL = 9 * CINL + 1, NTILE = (NCOL + 15) / 16;
-    const ModelLayout &L = a.lay;
     const int V = a.V, lane = threadIdx.x & 63;
     const int nq = lane & 15, kq = lane >> 4;
     const int co_a = nq < P ? nq : P - 1;          // rows 12..15 of the tile are never written back
-    const bool is_out = layer == L.L;
+    const int pslot = plane_slot(V);
     int bcol[NTILE];
     bool bone[NTILE];
 #pragma unroll
@@ -625,45 +668,19 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
 #pragma unroll
     for (int tl = 0; tl < NTILE; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gwave = __builtin_amdgcn_readfirstlane(gwave);
-    for (int n = gwave; n < a.N; n += nwaves) {
-        int vi = a.num_peds ? a.num_peds[n] : V;
-        vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));    // wave-uniform
+    // Scenes are dealt round-robin over the layer's waves.  Staging is NOT double-buffered on purpose: two
+    // images per wave halve the residency to one wave per SIMD, and this loop needs two to hide its LDS
+    // latency (measured slower, profiles/); a device-scope scene queue was slower too (dequeue latency).
+    float *cur = buf0;
+    (void)buf1;
+    for (int n = __builtin_amdgcn_readfirstlane(row_id); n < a.N; n += nrows) {
+        const int vi = wgrad_vi(a, n);
         if (vi == 0) continue;
-        const int SW = txp_sw(vi), npos = C * vi;
-        const float *wsn = a.ws + n * a.ws_stride;
-        // stage a_l (whole zero-bordered plane, position-major [(C+2)*SW][P]) and dz_l ([P][ld]) with LDS-DMA
-        const int ld = dz_stride(vi);
-        if (a.debug_skip & 64) {
-        } else if (is_out) {
-            wave_dma_copy(wsn + ws_plane_off(L, V, layer), plane, ((C + 2) * SW * P + 3) >> 2);
-            // the output conv's dz is dy itself: (C*P) rows of V floats, vi valid -> [P][ld]
-            const float *dyn = a.dy + (int64_t)n * (C * P) * V;
-            constexpr int U = 8;
-            for (int e0 = lane; e0 < P * npos; e0 += 64 * U) {
-                float dv[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = e0 + 64 * u;
-                    const int ec = e < P * npos ? e : 0;
-                    const int row = ec / vi, w = ec - row * vi;        // row = co*C + h
-                    dv[u] = dyn[(int64_t)row * V + w];
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int e = e0 + 64 * u;
-                    if (e < P * npos) {
-                        const int co = e / npos;
-                        dzs[co * ld + (e - co * npos)] = dv[u];
-                    }
-                }
-            }
-        } else {
-            wave_dma_copy(wsn + ws_plane_off(L, V, layer), plane, ((C + 2) * SW * P + 3) >> 2);
-            wave_dma_copy(a.dzg + ((int64_t)n * L.L + layer) * dz_slot(V), dzs, (P * ld + 3) >> 2);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(a.debug_skip & 64)) wgrad_stage<CINL>(a, layer, n, vi, cur, cur + pslot);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // image of scene n complete
         __builtin_amdgcn_wave_barrier();
+        const float *plane = cur, *dzs = cur + pslot;
+        const int SW = txp_sw(vi), npos = C * vi, ld = dz_stride(vi);
         int boff[NTILE];
 #pragma unroll
         for (int tl = 0; tl < NTILE; ++tl) {
@@ -671,8 +688,6 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
             boff[tl] = ((tap / 3 - 1) * SW + (tap % 3 - 1)) * P + ci;
         }
         // K loop over the scene's positions, 4 per MFMA; this lane walks p = kq, kq+4, ...
-        // Two steps per iteration: all 16 operand reads are issued before the 14 MFMAs, so the LDS latency
-        // of iteration i+1 hides behind the matrix pipe still draining iteration i.
         const int nsteps = (a.debug_skip & 128) ? 0 : (npos + 3) >> 2;
         const int nfull = vi >= 4 ? ((a.debug_skip & 128) ? 0 : (npos >> 2)) : 0;   // steps without a K tail
         int w = kq;                                  // vi >= 4 on the fast path: h = 0
@@ -719,7 +734,7 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
         __builtin_amdgcn_wave_barrier();
     }
     // one slab row per wave: [P][CINL][9] weights then [P] biases (the parameters' own order)
-    float *row = a.slab2 + wgrad_slab_base(layer, a.rows) + (int64_t)gwave * wgrad_row_len(layer);
+    float *row = a.slab2 + wgrad_slab_base(layer, a.rows) + (int64_t)row_id * wgrad_row_len(layer);
     if (kq < 3) {
 #pragma unroll
         for (int tl = 0; tl < NTILE; ++tl) {
@@ -744,15 +759,17 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void txp_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int wave = threadIdx.x >> 6;
-    const int per_wave = plane_slot(a.V) + dz_slot(a.V);
-    float *plane = sm + wave * per_wave;
-    float *dzs = plane + plane_slot(a.V);
-    const int layer = blockIdx.y;
-    const int gwave = blockIdx.x * WAVES + wave, nwaves = gridDim.x * WAVES;
+    const int image = plane_slot(a.V) + dz_slot(a.V);          // one staged scene: plane + dz
+    float *buf0 = sm + wave * image, *buf1 = buf0;
+    // blockIdx.x -> (layer, workgroup within the layer): layer l owns blocks [wg_begin[l], wg_begin[l+1])
+    int layer = 0;
+    while (layer < a.lay.L && (int)blockIdx.x >= a.wg_begin[layer + 1]) ++layer;
+    const int row_id = ((int)blockIdx.x - a.wg_begin[layer]) * WAVES + wave;      // slab row of this wave
+    const int nrows = (a.wg_begin[layer + 1] - a.wg_begin[layer]) * WAVES;          // waves of this layer
     if (layer == 0)
-        wgrad_layer<Cfg::T>(a, layer, plane, dzs, gwave, nwaves);
+        wgrad_layer<Cfg::T>(a, layer, buf0, buf1, row_id, nrows);
     else
-        wgrad_layer<Cfg::P>(a, layer, plane, dzs, gwave, nwaves);
+        wgrad_layer<Cfg::P>(a, layer, buf0, buf1, row_id, nrows);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -846,13 +863,15 @@ static int bwd_grid(const ModelLayout &L, int N, int V) {
     return grid < N ? grid : N;
 }
 
-// K2 launch geometry: waves per workgroup, workgroups per layer
+// K2 launch geometry: one persistent workgroup of `waves` waves per CU slot; the chip's slots are split
+// over the layers in proportion to their MFMA work (layer 0 has 5 column tiles, the others 7)
 struct WgradGeom {
-    int waves, grid_x, rows;
+    int waves, grid, rows;          // rows = slab rows per layer (max workgroups of a layer * waves)
+    int wg_begin[kMaxTxp + 2];
     size_t lds;
 };
 static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
-    const size_t per_wave = ((size_t)plane_slot(V) + dz_slot(V)) * sizeof(float);
+    const size_t per_wave = (size_t)(plane_slot(V) + dz_slot(V)) * sizeof(float);
     if (per_wave > (size_t)kLdsBytes) return false;
     int waves = env_waves("STG_WGRAD_WAVES", 4);
     while (waves > 1 && per_wave * waves > (size_t)kLdsBytes) waves >>= 1;
@@ -860,17 +879,28 @@ static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
     g->lds = per_wave * waves;
     int per_cu = (int)(kLdsBytes / g->lds);
     if (per_cu * waves > 8) per_cu = 8 / waves > 0 ? 8 / waves : 1;
+    if (per_cu < 1) per_cu = 1;
     int total = kNumCU * per_cu;                       // resident workgroups on the chip
-    int gx = total / (L.L + 1);
     if (const char *e = getenv("STG_WGRAD_GRID")) {
         const int v = atoi(e);
-        if (v > 0) gx = v;
+        if (v > 0) total = v;
     }
-    if (gx < 1) gx = 1;
-    const int need = (N + waves - 1) / waves;
-    if (gx > need) gx = need;
-    g->grid_x = gx;
-    g->rows = gx * waves;
+    const int nl = L.L + 1;
+    if (total < nl) total = nl;
+    const int need = (N + waves - 1) / waves;          // never more workgroups per layer than scenes need
+    const int wsum = 6 + 7 * (nl - 1);      // per item: same staging bytes, 5 vs 7 column tiles of MFMAs
+    int begin = 0, maxw = 0;
+    for (int l = 0; l < nl; ++l) {
+        int cnt = (int)((int64_t)total * (l == 0 ? 6 : 7) / wsum);
+        if (cnt < 1) cnt = 1;
+        if (cnt > need) cnt = need;
+        g->wg_begin[l] = begin;
+        begin += cnt;
+        if (cnt > maxw) maxw = cnt;
+    }
+    g->wg_begin[nl] = begin;
+    g->grid = begin;
+    g->rows = maxw * waves;
     return true;
 }
 
@@ -885,6 +915,7 @@ static int64_t bwd_scratch_floats(const ModelLayout &L, int N, int V) {
         fl += wgrad_slab_base(L.L + 1, g.rows);
         fl = (fl + 3) & ~(int64_t)3;
         fl += (int64_t)N * L.L * dz_slot(V);
+        fl += 16;                                                // K2 scene-queue heads (one int per layer)
         if (txp_wave_fits(L, V)) {
             fl += (int64_t)N * (Cfg::C * Cfg::T * V);            // d(a_0) hand-off
             fl = (fl + 3) & ~(int64_t)3;
@@ -941,12 +972,15 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     float *slab2 = scratch + off;
     WgradGeom wg{};
     float *dzg = nullptr;
+    int *k2_counters = nullptr;
     if (L.n_txp > 0) {
         STG_REQUIRE(wgrad_geom(L, N, V, &wg), STG_ELDS, "stg_model_bwd: V=%d does not fit LDS (wgrad)", V);
         off += wgrad_slab_base(L.L + 1, wg.rows);
         off = (off + 3) & ~(int64_t)3;
         dzg = scratch + off;
         off += (int64_t)N * L.L * dz_slot(V);
+        k2_counters = reinterpret_cast<int *>(scratch + off);
+        off += 16;
     }
     const bool wave_path = txp_wave_fits(L, V);
     float *da0 = nullptr, *slopes = nullptr;
@@ -965,7 +999,6 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         TxpBwdArgs t{};
         t.lay = L; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V; t.dy = dy; t.ws = ws;
         t.ws_stride = a.ws_stride; t.dzg = dzg; t.da0 = da0; t.slopes = slopes;
-        t.counter = reinterpret_cast<int *>(scratch + (((slopes - scratch) + (int64_t)N * L.n_txp + 3) & ~(int64_t)3));
         if (!(a.debug_skip & 2)) {
             const int rcw = launch_txp_bwd_wave(t, st);
             if (rcw != STG_OK) return rcw;
@@ -1001,8 +1034,13 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         WgradArgs w{};
         w.lay = L; w.num_peds = num_peds; w.N = N; w.V = V; w.dy = dy; w.ws = ws; w.dzg = dzg;
         w.ws_stride = a.ws_stride; w.slab2 = slab2; w.rows = wg.rows; w.debug_skip = a.debug_skip;
+        w.counters = k2_counters;
+        for (int l = 0; l <= L.L + 1; ++l) w.wg_begin[l] = wg.wg_begin[l];
         if (!(a.debug_skip & 1)) {
-            const dim3 g2(wg.grid_x, L.L + 1);
+            // unused slab rows (layers with fewer workgroups than `rows`) must read as zero
+            hipError_t e0 = hipMemsetAsync(slab2, 0, sizeof(float) * wgrad_slab_base(L.L + 1, wg.rows), st);
+            if (e0 != hipSuccess) return hip_fail(e0, "stg_model_bwd: K2 slab memset");
+            const dim3 g2(wg.grid);
 #define STG_LAUNCH_WG(W)                                                                                     \
     do {                                                                                                     \
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_wgrad_kernel<W>),            \

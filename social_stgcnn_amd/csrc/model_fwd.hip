@@ -84,12 +84,20 @@ __device__ void stgcn_block_fwd(const FwdArgs &a, const BlockLayout &b, int n, i
         float csum = 0.f;
         const float *at = an + (int64_t)t * V * V + w;
         const float *xt = X + t * vi;
-#pragma unroll 4
-        for (int v = 0; v < vi; ++v) {
-            const float av = at[(int64_t)v * V];
-            csum += av;
+        // column w of A[n,t]: 16 row loads in flight per lane (the loop is HBM-latency-bound otherwise)
+        constexpr int UA = 16;
+        for (int v0 = 0; v0 < vi; v0 += UA) {
+            float av[UA];
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) ax[ci] = fmaf(xt[ci * T * vi + v], av, ax[ci]);
+            for (int u = 0; u < UA; ++u) av[u] = (v0 + u) < vi ? at[(int64_t)(v0 + u) * V] : 0.f;
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                if (v0 + u < vi) {
+                    csum += av[u];
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) ax[ci] = fmaf(xt[ci * T * vi + v0 + u], av[u], ax[ci]);
+                }
+            }
         }
         cs[q] = csum;
         if (wsn) {
@@ -550,7 +558,6 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         TxpFwdArgs t{};
         t.lay = a.lay; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V;
         t.a0g = scratch; t.y = y; t.ws = ws; t.ws_stride = a.ws_stride;
-        t.counter = reinterpret_cast<int *>(scratch + (int64_t)N * plane_slot(V));
         t.stamps = getenv("STG_STAMPS") ? reinterpret_cast<unsigned long long *>(scratch + (int64_t)N * plane_slot(V) + 4) : nullptr;
         return launch_txp_fwd_wave(t, st);
     }

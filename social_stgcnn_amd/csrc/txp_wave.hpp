@@ -13,7 +13,6 @@ struct TxpFwdArgs {
     float *y;              // (N, C, P, V)
     float *ws;             // per-scene workspace or null (inference)
     int64_t ws_stride;
-    int *counter;          // 16 bytes of scratch: the scene queue head (zeroed by the launcher)
     unsigned long long *stamps;   // diagnostic build only (STG_STAMPS=1): [N][16] s_memtime stamps, else null
 };
 
@@ -28,7 +27,6 @@ struct TxpBwdArgs {
     float *dzg;            // [N][L][dz_slot(V)]   dz_l of the hidden layers for the weight-gradient GEMM
     float *da0;            // [N][C*T*V]           gradient w.r.t. the st_gcn block output
     float *slopes;         // [N][n_txp]           per-scene PReLU slope gradients
-    int *counter;          // 16 bytes of scratch: the scene queue head (zeroed by the launcher)
 };
 
 // true when the wave-per-scene path serves this model / V (else the workgroup-per-scene kernels run)
