@@ -64,6 +64,8 @@ __host__ __device__ inline int64_t wgrad_slab_base(int layer, int rows) {
 
 constexpr int kRedMax = 96;   // widest block reduction (values)
 
+__device__ __forceinline__ void wave_dma_copy(const float *__restrict__ src, float *lds_dst, int nvec);
+
 // Sum K per-thread values over the workgroup; totals land in tot[0..K) (LDS), visible to every
 // thread on return.
 template <int K, int WAVES>
@@ -162,7 +164,7 @@ template <int CIN, int WAVES>
 __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, int vi, float *D, float *H1,
                                 float *DH2, float *DB1, float *red, float *tot, float *gsm, const float *wsn,
                                 const float *xin_ws /* block input saved by the previous block, or null */,
-                                float *dxs, float *dxg) {
+                                float *dxs, float *dxg, const float *lds_saved /* staged [ax|cs|g|h2] or null */) {
     constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, NT = WAVES * 64, TP = T + 2;
     const int tid = threadIdx.x, V = a.V, cnt = T * vi;
     const float *P_ = a.params;
@@ -171,6 +173,13 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
     const float *wsa = wsn + a.lay.ws_hdr_floats;     // saved arrays sit behind the header
     const float *w_ax = wsa + (int64_t)b.ws_ax * V, *w_cs = wsa + (int64_t)b.ws_cs * V;
     const float *w_g = wsa + (int64_t)b.ws_g * V, *w_h2 = wsa + (int64_t)b.ws_h2 * V;
+    if (lds_saved) {      // the kernel staged the four arrays into LDS with one DMA burst (compact, 4-float padded)
+        const int n_ax = (CIN * T * vi + 3) & ~3, n_cs = (T * vi + 3) & ~3, n_g = (C * T * vi + 3) & ~3;
+        w_ax = lds_saved;
+        w_cs = w_ax + n_ax;
+        w_g = w_cs + n_cs;
+        w_h2 = w_g + n_g;
+    }
     const float *hdr = wsn + b.ws_hdr;
     float m1[C], r1[C], m2[C], r2[C], mr[C], rr[C];
 #pragma unroll
@@ -464,14 +473,17 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
     const int scmax = txp_sc(V);
     const int plane_floats = P * scmax;
     // st_gcn phase needs 3 planes: h1 [C][T+2][V], dh2 [C][T+2][V], db1 [C][T][V]
-    const int st_floats = (2 * C * (T + 2) + C * T) * V;
-    const int reg_floats = plane_floats > st_floats ? plane_floats : st_floats;
+    const bool lean = a.da0 != nullptr && a.dx == nullptr && L.n_blocks == 1;    // blocks only, no dx
+    const int st_floats = lean ? 2 * C * (T + 2) * V : (2 * C * (T + 2) + C * T) * V;
+    const int reg_floats = lean ? st_floats : (plane_floats > st_floats ? plane_floats : st_floats);
+    const int dcur_floats = lean ? C * T * V : P * C * V;
     const int n_small = L.n_blk_params + L.n_txp;
     float *gsm = sm;                                  // [n_small] block parameters, then the PReLU slopes
     float *dzb = gsm + ((n_small + 3) & ~3);          // [P][SC]   dz_l, zero-bordered (aliases the st_gcn planes)
     float *dcur = dzb + reg_floats;                   // [P*C*V]   gradient w.r.t. the layer output
-    float *red = dcur + P * C * V;                    // [WAVES*kRedMax]
+    float *red = dcur + dcur_floats;                  // [WAVES*kRedMax]
     float *tot = red + WAVES * kRedMax;               // [kRedMax]
+    float *saved = tot + kRedMax;                     // lean: [ax|cs|g|h2] of the scene, staged by LDS-DMA
     const float *Pm = a.params;
 
     for (int e = tid; e < n_small; e += NT) gsm[e] = 0.f;
@@ -492,8 +504,26 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
         const float *dyn = a.dy + (int64_t)n * out_rows * V;
         __syncthreads();
         if (a.da0) {
-            const float *src = a.da0 + (int64_t)n * (C * T * V);
-            for (int e = tid; e < C * T * vi; e += NT) dcur[e] = src[e];
+            if (lean) {
+                // ONE burst of LDS-DMA brings d(a_0) and the four saved arrays of the block: the reduction passes
+                // below then run from LDS instead of paying an HBM round trip per pass
+                const BlockLayout &b0 = L.blk[0];
+                const float *wsa = wsn + L.ws_hdr_floats;
+                const int wave = tid >> 6;
+                const int n_ax = (b0.cin * T * vi + 3) & ~3, n_cs = (T * vi + 3) & ~3, n_g = (C * T * vi + 3) & ~3;
+                const float *srcs[5] = {a.da0 + (int64_t)n * (C * T * V), wsa + (int64_t)b0.ws_ax * V,
+                                        wsa + (int64_t)b0.ws_cs * V, wsa + (int64_t)b0.ws_g * V,
+                                        wsa + (int64_t)b0.ws_h2 * V};
+                float *dsts[5] = {dcur, saved, saved + n_ax, saved + n_ax + n_cs, saved + n_ax + n_cs + n_g};
+                const int cnts[5] = {n_g >> 2, n_ax >> 2, n_cs >> 2, n_g >> 2, n_g >> 2};
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    if (k % WAVES == wave) wave_dma_copy(srcs[k], dsts[k], cnts[k]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                const float *src = a.da0 + (int64_t)n * (C * T * V);
+                for (int e = tid; e < C * T * vi; e += NT) dcur[e] = src[e];
+            }
             __syncthreads();
         } else if (L.n_txp > 0) {
             // ---- TXP-CNN backward (input-gradient chain) -------------------------------------------
@@ -569,17 +599,18 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
             __syncthreads();
         }
         // ---- st_gcn blocks, last to first ------------------------------------------------------
-        float *H1 = dzb, *DH2 = dzb + C * (T + 2) * V, *DB1 = DH2 + C * (T + 2) * V;
+        // lean image: db1 reuses the du plane (dcur), which is dead once dh2 / dr have been formed
+        float *H1 = dzb, *DH2 = dzb + C * (T + 2) * V, *DB1 = lean ? dcur : DH2 + C * (T + 2) * V;
         for (int j = L.n_blocks - 1; j >= 0 && !(a.debug_skip & 4); --j) {
             const float *xin = j > 0 ? wsn + L.ws_hdr_floats + (int64_t)L.blk[j - 1].ws_s * V : nullptr;
             float *dxs = j > 0 ? dcur : nullptr;
             float *dxg = j == 0 ? dxn : nullptr;
             if (L.blk[j].cin == Cfg::CIN0)
                 stgcn_block_bwd<Cfg::CIN0, WAVES>(a, L.blk[j], n, vi, dcur, H1, DH2, DB1, red, tot, gsm, wsn, xin,
-                                                  dxs, dxg);
+                                                  dxs, dxg, lean ? saved : nullptr);
             else
                 stgcn_block_bwd<Cfg::C, WAVES>(a, L.blk[j], n, vi, dcur, H1, DH2, DB1, red, tot, gsm, wsn, xin, dxs,
-                                               dxg);
+                                               dxg, lean ? saved : nullptr);
         }
     }
     __syncthreads();
@@ -833,13 +864,14 @@ static int env_waves(const char *name, int dflt) {
     return dflt;
 }
 
-static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves) {
+static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves, bool lean = false) {
     const int plane = Cfg::P * txp_sc(V);
-    const int st = (2 * Cfg::C * (Cfg::T + 2) + Cfg::C * Cfg::T) * V;
-    const int reg = plane > st ? plane : st;
+    const int st = lean ? 2 * Cfg::C * (Cfg::T + 2) * V : (2 * Cfg::C * (Cfg::T + 2) + Cfg::C * Cfg::T) * V;
+    const int reg = lean ? st : (plane > st ? plane : st);
+    const int dcur = lean ? Cfg::C * Cfg::T * V : Cfg::P * Cfg::C * V;
     const int n_small = L.n_blk_params + L.n_txp;
-    const size_t fl = ((n_small + 3) & ~3) + (size_t)reg + (size_t)Cfg::P * Cfg::C * V + (size_t)waves * kRedMax +
-                      kRedMax;
+    const int saved = lean ? (Cfg::CIN0 + 1 + 2 * Cfg::C) * Cfg::T * V + 16 : 0;       // [ax|cs|g|h2] + padding
+    const size_t fl = ((n_small + 3) & ~3) + (size_t)reg + (size_t)dcur + (size_t)waves * kRedMax + kRedMax + saved;
     return fl * sizeof(float);
 }
 
@@ -847,9 +879,9 @@ static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves) {
 // barriers in its ~15 block reductions), more waves only when a scene's rows no longer fit one wave's registers
 static int bwd_waves(int V) { return env_waves("STG_BWD_WAVES", V <= 40 ? 1 : (V <= 80 ? 4 : 8)); }
 
-static int bwd_grid(const ModelLayout &L, int N, int V) {
+static int bwd_grid(const ModelLayout &L, int N, int V, bool lean = false) {
     const int waves = bwd_waves(V);
-    const size_t lds = bwd_lds_bytes(L, V, waves);
+    const size_t lds = bwd_lds_bytes(L, V, waves, lean);
     if (lds > (size_t)kLdsBytes) return -1;
     int per_cu = (int)(kLdsBytes / lds);
     const int by_waves = 8 / waves > 0 ? 8 / waves : 1;   // 256-VGPR kernel: 2 waves per SIMD
@@ -905,8 +937,12 @@ static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
 }
 
 static int64_t bwd_scratch_floats(const ModelLayout &L, int N, int V) {
-    const int g1 = bwd_grid(L, N, V);
+    int g1 = bwd_grid(L, N, V);
     if (g1 < 0) return -1;
+    if (txp_wave_fits(L, V)) {                 // the lean (blocks-only, no dx) image admits more workgroups
+        const int g2 = bwd_grid(L, N, V, true);
+        if (g2 > g1) g1 = g2;
+    }
     int64_t fl = (int64_t)g1 * (L.n_blk_params + L.n_txp);
     fl = (fl + 3) & ~(int64_t)3;
     if (L.n_txp > 0) {
@@ -960,11 +996,12 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         if (e != hipSuccess) return hip_fail(e, "stg_model_bwd: memset");
         return STG_OK;
     }
+    const bool lean = txp_wave_fits(L, V) && dx == nullptr && L.n_blocks == 1;
     const int waves = bwd_waves(V);
-    const size_t lds = bwd_lds_bytes(L, V, waves);
+    const size_t lds = bwd_lds_bytes(L, V, waves, lean);
     STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_bwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
                 kLdsBytes);
-    const int grid = bwd_grid(L, N, V);
+    const int grid = bwd_grid(L, N, V, lean);
     const int n_small = L.n_blk_params + L.n_txp;
     // scratch carve (must match bwd_scratch_floats)
     float *slab1 = scratch;

@@ -529,7 +529,7 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     a.a0g = wave_path ? scratch : nullptr;
     if (const char *e = getenv("STG_DEBUG_SKIP")) a.debug_skip = atoi(e);
     int waves = V <= 12 ? 1 : (V <= 40 ? 2 : (V <= 80 ? 4 : 8));
-    if (wave_path) waves = V <= 4 ? 1 : (V <= 12 ? 2 : 4);     // blocks only: one lane per (t, w) column
+    if (wave_path) waves = V <= 4 ? 1 : 2;     // blocks only (measured at V=32: 2 waves 74 us, 4: 79, 1: 96, 8: 172)
     if (const char *e = getenv("STG_FWD_WAVES")) {
         const int w = atoi(e);
         if (w == 1 || w == 2 || w == 4 || w == 8) waves = w;
