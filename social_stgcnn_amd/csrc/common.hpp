@@ -32,10 +32,20 @@ constexpr int kLdsBytes = 160 * 1024;
 constexpr int kNumCU = 256;
 
 // ---- device helpers --------------------------------------------------------------------
+// Sum over the 64 lanes of the wave, result in every lane.  Six DPP-modified v_add (quad swaps, row
+// mirrors, row broadcasts -- pure VALU, no LDS crossbar, no s_waitcnt) leave the total in lane 63;
+// v_readlane broadcasts it.  Needs all 64 lanes active (call from wave-uniform control flow).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+#define STG_DPP_ADD(ctrl, row_mask)                                                                              \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (row_mask), 0xf, false))
+    STG_DPP_ADD(0xB1, 0xf);    // quad_perm [1,0,3,2]
+    STG_DPP_ADD(0x4E, 0xf);    // quad_perm [2,3,0,1]
+    STG_DPP_ADD(0x141, 0xf);   // row_half_mirror
+    STG_DPP_ADD(0x140, 0xf);   // row_mirror            -> every lane holds its 16-lane row sum
+    STG_DPP_ADD(0x142, 0xa);   // row_bcast15 into rows 1, 3
+    STG_DPP_ADD(0x143, 0xc);   // row_bcast31 into rows 2, 3 -> lane 63 holds the wave sum
+#undef STG_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -62,7 +62,7 @@ __host__ __device__ inline int64_t wgrad_slab_base(int layer, int rows) {
     return layer == 0 ? 0 : (int64_t)rows * (wgrad_row_len(0) + (int64_t)(layer - 1) * wgrad_row_len(1));
 }
 
-constexpr int kRedMax = 96;   // widest block reduction (values)
+constexpr int kRedMax = 32;   // widest block reduction (values)
 
 __device__ __forceinline__ void wave_dma_copy(const float *__restrict__ src, float *lds_dst, int nvec);
 
@@ -309,40 +309,51 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
             __syncthreads();
         }
     }
-    // ---- B3: temporal conv gradients, dh1 -> db1, BatchNorm tcn.0 reductions ------------------------
+    // ---- B3a: temporal conv weight gradients, one temporal tap at a time (25 accumulators, not 75) -------
+    for (int dt = 0; dt < KT; ++dt) {
+        float s[C * C];
+#pragma unroll
+        for (int k = 0; k < C * C; ++k) s[k] = 0.f;
+        for (int q = tid; q < cnt; q += NT) {
+            const int t = q / vi, w = q - t * vi;
+            float dh[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) dh[c] = DH2[(c * TP + t + 1) * vi + w];
+#pragma unroll
+            for (int ci = 0; ci < C; ++ci) {
+                // h1 at t + dt - 1 (t-padded plane, rows 0 and T+1 are zero)
+                const float hv = H1[(ci * TP + t + dt) * vi + w];
+#pragma unroll
+                for (int c = 0; c < C; ++c) s[c * C + ci] = fmaf(dh[c], hv, s[c * C + ci]);
+            }
+        }
+        block_reduce<C * C, WAVES>(s, red, tot);
+        for (int k = tid; k < C * C; k += NT) gsm[b.tcn_w + k * KT + dt] += tot[k];
+    }
+    // ---- B3b: dh1 -> db1, conv bias gradient, BatchNorm tcn.0 reductions, PReLU slope ---------------------
     {
-        constexpr int KW = C * C * KT;                 // 75 weight gradients
-        constexpr int K3 = KW + C + 2 * C + 1;         // + conv bias, sum db1, sum db1*xhat1, prelu slope
+        constexpr int K3 = 3 * C + 1;                  // conv bias, sum db1, sum db1*xhat1, prelu slope
         float s[K3];
 #pragma unroll
         for (int k = 0; k < K3; ++k) s[k] = 0.f;
         const float a1 = P_[b.prelu1];
         for (int q = tid; q < cnt; q += NT) {
             const int t = q / vi, w = q - t * vi;
-            float dh[C], dh1[C];
+            float dh1[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                dh[c] = DH2[(c * TP + t + 1) * vi + w];
-                s[KW + c] += dh[c];
+                s[c] += DH2[(c * TP + t + 1) * vi + w];
                 dh1[c] = 0.f;
             }
+            // input gradient: dh1[ci][t] = sum_{c,dt} Wt[c][ci][dt] dh2[c][t - dt + 1]
 #pragma unroll
-            for (int dt = 0; dt < KT; ++dt) {
-#pragma unroll
-                for (int ci = 0; ci < C; ++ci) {
-                    // weight gradient: h1 at t + dt - 1 (t-padded plane, rows 0 and T+1 are zero)
-                    const float hv = H1[(ci * TP + t + dt) * vi + w];
-#pragma unroll
-                    for (int c = 0; c < C; ++c) s[(c * C + ci) * KT + dt] = fmaf(dh[c], hv, s[(c * C + ci) * KT + dt]);
-                }
-                // input gradient: dh1[ci][t] = sum_{c,dt} Wt[c][ci][dt] dh2[c][t - dt + 1]
+            for (int dt = 0; dt < KT; ++dt)
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const float dv = DH2[(c * TP + t - dt + 2) * vi + w];
 #pragma unroll
                     for (int ci = 0; ci < C; ++ci) dh1[ci] = fmaf(P_[b.tcn_w + (c * C + ci) * KT + dt], dv, dh1[ci]);
                 }
-            }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const int i = (c * T + t) * vi + w;
@@ -351,31 +362,27 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
                 float db = dh1[c];
                 if (!(b1 > 0.f)) {
                     db = a1 * dh1[c];
-                    s[KW + 3 * C] = fmaf(dh1[c], b1, s[KW + 3 * C]);
+                    s[3 * C] = fmaf(dh1[c], b1, s[3 * C]);
                 }
                 DB1[i] = db;
-                s[KW + C + c] += db;
-                s[KW + 2 * C + c] = fmaf(db, x1, s[KW + 2 * C + c]);
+                s[C + c] += db;
+                s[2 * C + c] = fmaf(db, x1, s[2 * C + c]);
             }
         }
         block_reduce<K3, WAVES>(s, red, tot);
         for (int k = tid; k < K3; k += NT) {
             const float v = tot[k];
-            if (k < KW) gsm[b.tcn_w + k] += v;
-            else if (k < KW + C) gsm[b.tcn_b + k - KW] += v;
-            else if (k < KW + 2 * C) gsm[b.bn1_b + k - KW - C] += v;
-            else if (k < KW + 3 * C) gsm[b.bn1_g + k - KW - 2 * C] += v;
+            if (k < C) gsm[b.tcn_b + k] += v;
+            else if (k < 2 * C) gsm[b.bn1_b + k - C] += v;
+            else if (k < 3 * C) gsm[b.bn1_g + k - 2 * C] += v;
             else gsm[b.prelu1] += v;
         }
     }
     float mdb[C], mdbx[C];
-    {
-        constexpr int KW = C * C * KT;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            mdb[c] = train ? tot[KW + C + c] * inv_cnt : 0.f;
-            mdbx[c] = train ? tot[KW + 2 * C + c] * inv_cnt : 0.f;
-        }
+    for (int c = 0; c < C; ++c) {
+        mdb[c] = train ? tot[C + c] * inv_cnt : 0.f;
+        mdbx[c] = train ? tot[2 * C + c] * inv_cnt : 0.f;
     }
     // ---- B4: dg; gcn 1x1 conv gradients; d(aggregated input) -------------------------------------
     {
@@ -519,6 +526,15 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
 #pragma unroll
                 for (int k = 0; k < 5; ++k)
                     if (k % WAVES == wave) wave_dma_copy(srcs[k], dsts[k], cnts[k]);
+                // the (strided) block input x[n] rides along into LDS: [cin][T][vi]
+                {
+                    const float *xn = a.x + n * a.x_sn;
+                    float *xl = saved + n_ax + n_cs + 2 * n_g;
+                    for (int e = tid; e < b0.cin * T * vi; e += NT) {
+                        const int v = e % vi, ct = e / vi, t = ct % T, c = ct / T;
+                        xl[e] = xn[c * a.x_sc + t * a.x_st + v * a.x_sv];
+                    }
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
                 const float *src = a.da0 + (int64_t)n * (C * T * V);
@@ -603,6 +619,10 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
         float *H1 = dzb, *DH2 = dzb + C * (T + 2) * V, *DB1 = lean ? dcur : DH2 + C * (T + 2) * V;
         for (int j = L.n_blocks - 1; j >= 0 && !(a.debug_skip & 4); --j) {
             const float *xin = j > 0 ? wsn + L.ws_hdr_floats + (int64_t)L.blk[j - 1].ws_s * V : nullptr;
+            if (lean) {       // x[n] was staged behind the saved arrays
+                const int n_ax = (L.blk[0].cin * T * vi + 3) & ~3, n_cs = (T * vi + 3) & ~3, n_g = (C * T * vi + 3) & ~3;
+                xin = saved + n_ax + n_cs + 2 * n_g;
+            }
             float *dxs = j > 0 ? dcur : nullptr;
             float *dxg = j == 0 ? dxn : nullptr;
             if (L.blk[j].cin == Cfg::CIN0)
@@ -870,7 +890,7 @@ static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves, bool lean = 
     const int reg = lean ? st : (plane > st ? plane : st);
     const int dcur = lean ? Cfg::C * Cfg::T * V : Cfg::P * Cfg::C * V;
     const int n_small = L.n_blk_params + L.n_txp;
-    const int saved = lean ? (Cfg::CIN0 + 1 + 2 * Cfg::C) * Cfg::T * V + 16 : 0;       // [ax|cs|g|h2] + padding
+    const int saved = lean ? (2 * Cfg::C + 1 + 2 * Cfg::C) * Cfg::T * V + 16 : 0;      // [ax|cs|g|h2|x] + padding (cin <= C)
     const size_t fl = ((n_small + 3) & ~3) + (size_t)reg + (size_t)dcur + (size_t)waves * kRedMax + kRedMax + saved;
     return fl * sizeof(float);
 }
