@@ -130,8 +130,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL ("nccl") over xGMI on a real node; STG_DIST_BACKEND=gloo lets several ranks share ONE GPU to
+        # rehearse the multi-rank code path on a single-GPU box
+        backend = os.environ.get("STG_DIST_BACKEND", "nccl")
+        local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 

@@ -439,3 +439,80 @@ def test_full_size_properties(dev):
     assert torch.isfinite(y0).all() and torch.isfinite(g0).all()
     # symmetric Laplacian, zero first frame, rows of D^-1/2 (D-A) D^-1/2 in [-1, 1]
     assert torch.equal(A, A.transpose(2, 3)) and torch.all(A[:, 0] == 0) and float(A.abs().max()) <= 1.0
+
+
+def _synthetic_scene(v, seed):
+    rng = np.random.default_rng(seed)
+    rel = np.zeros((v, 2, 20), np.float32)
+    rel[:, :, 1:] = np.round(rng.uniform(-0.6, 0.6, (v, 2, 19)), 4).astype(np.float32)
+    return rel
+
+
+@pytest.mark.parametrize("v,force_generic", [(128, False), (96, False), (17, True), (57, True), (68, False), (69, False)])
+def test_large_v_and_workgroup_path(dev, v, force_generic, monkeypatch):
+    """cfg5-style dense crowds (V=128 needs the workgroup-per-scene kernels: 8 waves, ~110 KB of LDS) and the
+    workgroup-per-scene path forced on small scenes (STG_NO_WAVE_PATH) -- forward, loss, every gradient and
+    the BatchNorm buffers against the oracle; 68 / 69 straddle the limit of the wave-per-scene path."""
+    from social_stgcnn_amd import ops
+    from social_stgcnn_amd.metrics import bivariate_loss
+    O = _oracle()
+    if force_generic:
+        monkeypatch.setenv("STG_NO_WAVE_PATH", "1")
+    n = 3
+    rels = [_synthetic_scene(v, 100 + v + i) for i in range(n)]
+    m = _model(dev, seed=v).train()
+    state = {k: val.detach().cpu().clone() for k, val in m.state_dict().items()}
+    keys = [k for k, _ in m.named_parameters()]
+    # The reference runs in FLOAT64: PReLU's derivative jumps at 0, so a pre-activation within fp32 rounding of
+    # zero (about one element in 10^5 scenes-elements) makes two correct fp32 implementations -- even the
+    # oracle with 1 vs 4 CPU threads -- disagree on a gradient by O(upstream gradient).  fp64 is the arbiter.
+    state64 = {k: (val.double() if val.is_floating_point() else val.clone()) for k, val in state.items()}
+    params = {k: state64[k].clone().requires_grad_(True) for k in keys}
+    work = dict(state64)
+    work.update(params)
+    ref_losses, ref_pred = [], []
+    for rel in rels:
+        nodes, lap = O.seq_to_graph_np(rel[:, :, :8])
+        tgt, _ = O.seq_to_graph_np(rel[:, :, 8:])
+        l, vp = O.scene_loss(work, torch.from_numpy(nodes).double().unsqueeze(0).permute(0, 3, 1, 2),
+                             torch.from_numpy(lap).double(), torch.from_numpy(tgt).double(), True)
+        ref_losses.append(l)
+        ref_pred.append(vp.detach())
+    torch.stack(ref_losses).sum().backward()
+    rel_d = torch.from_numpy(np.stack(rels)).to(dev)
+    nodes_d, adj_d = ops.adj_build(rel_d[..., :8])
+    tgt_d = rel_d[..., 8:].permute(0, 3, 1, 2).contiguous()
+    y, _ = m(nodes_d.permute(0, 3, 1, 2), adj_d)
+    losses = bivariate_loss(y.permute(0, 2, 3, 1), tgt_d)
+    losses.sum().backward()
+    for i in range(n):
+        assert _maxdiff(y[i].detach().permute(1, 2, 0).cpu().numpy(), ref_pred[i].numpy()) < 5e-5, i
+    assert _maxdiff(losses.detach().cpu().numpy(), torch.stack(ref_losses).detach().numpy()) < 5e-5
+    errs = _grad_errors(((name, p.grad) for name, p in m.named_parameters()),
+                        lambda name: None if params[name].grad is None else params[name].grad.numpy())
+    bad = {k: e for k, e in errs.items() if e > 5e-4}
+    assert not bad, bad
+    for k, val in m.state_dict().items():
+        if "running" in k:
+            assert _maxdiff(val.cpu().numpy(), work[k].numpy()) < 2e-6, k
+
+
+def test_inference_matches_training_forward(dev):
+    """eval()/no_grad (no activation saves, running statistics) on a ragged batch == per-scene oracle."""
+    O = _oracle()
+    a = load_golden("adj_cases.npz")
+    w = _state(load_golden("weights_eth.npz"))
+    m = _model(dev, state=w).eval()
+    vs = [3, 32, 8, 57, 2]
+    vmax = 57
+    x = torch.zeros(len(vs), 2, 8, vmax)
+    A = torch.zeros(len(vs), 8, vmax, vmax)
+    for i, v in enumerate(vs):
+        x[i, :, :, :v] = torch.from_numpy(a["nodes_%d" % v]).permute(2, 0, 1)
+        A[i, :, :v, :v] = torch.from_numpy(a["lap_%d" % v])
+    with torch.no_grad():
+        y, _ = m(x.to(dev), A.to(dev), num_peds=vs)
+    f = load_golden("forward_eval.npz")
+    for i, v in enumerate(vs):
+        assert _maxdiff(y[i, :, :, :v].cpu().numpy(), f["vpred_%d" % v][0]) < 2e-5, v
+        assert torch.all(y[i, :, :, v:] == 0)
