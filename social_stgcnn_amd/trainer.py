@@ -35,27 +35,38 @@ def allreduce_flat(flat, group=None):
     return flat
 
 
-def fold_bn_across_ranks(before, after, n_local, momentum, group=None):
-    """Exact sequential-fold of BatchNorm running statistics over ranks.
+def bn_fold_scale(counts, rank, momentum):
+    """Weights of the cross-rank BatchNorm fold for rank `rank` given every rank's scene count:
+    (decay of this rank's own shard, factor its contribution is scaled by, total decay)."""
+    keep = 1.0 - momentum
+    own = keep ** int(counts[rank])
+    later = keep ** int(sum(counts[rank + 1:]))
+    total = keep ** int(sum(counts))
+    return own, later, total
+
+
+def fold_bn_across_ranks(before, after, n_local, momentum, group=None, counts=None):
+    """Exact sequential-fold of BatchNorm running statistics over ranks with ONE all-reduce.
 
     Every rank updated its own copy `before -> after` with its n_local scenes:
         after = (1-m)^n_local * before + acc_r .
-    The equivalent of ONE process seeing rank 0's scenes, then rank 1's, ... is
-        r <- (1-m)^n_r * r + acc_r   for r = 0..R-1   (starting from the common `before`).
-    Returns the folded statistics (same on every rank).
-    """
+    ONE process seeing rank 0's scenes, then rank 1's, ... would end at
+        before * prod_j (1-m)^n_j + sum_r acc_r * prod_{j>r} (1-m)^n_j ,
+    so each rank scales its acc_r by the decay of the ranks after it and the sum is a plain all-reduce
+    (the trainer packs it behind the gradient: one collective per step).  `counts` = scenes per rank
+    (gathered when not given).  Returns the folded statistics (same on every rank)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return after
-    world = dist.get_world_size(group)
-    decay = (1.0 - momentum) ** int(n_local)
-    acc = after - decay * before
-    pack = torch.cat([acc.reshape(-1), torch.tensor([decay], dtype=acc.dtype, device=acc.device)])
-    gathered = [torch.empty_like(pack) for _ in range(world)]
-    dist.all_gather(gathered, pack, group=group)
-    r = before.clone()
-    for g in gathered:
-        r = r * g[-1] + g[:-1].view_as(r)
-    return r
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if counts is None:
+        t = torch.tensor([int(n_local)], dtype=torch.int64, device=after.device)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+        counts = [int(p.item()) for p in parts]
+    own, later, total = bn_fold_scale(counts, rank, momentum)
+    contrib = (after - own * before) * later
+    dist.all_reduce(contrib, op=dist.ReduceOp.SUM, group=group)
+    return before * total + contrib
 
 
 def broadcast_module(model, src=0, group=None):
@@ -109,7 +120,9 @@ class Trainer:
         """forward_backward + gradient all-reduce + BatchNorm fold across ranks + SGD update."""
         model = self.model
         if self.world > 1:
-            before = [b.detach().clone() for b in self._bn_buffers()]
+            model.flat_parameters()                       # make sure the flat views exist
+            model._pb.ensure(self._bn_buffers())
+            before = model._pb.flat.clone()
         total, losses, y = self.forward_backward(x, adj, target, num_peds, weights)
         flat_p = model.flat_parameters()
         flat_g = self._flat_grad()
@@ -117,8 +130,8 @@ class Trainer:
             allreduce_flat(flat_g, self.group)
             n_local = int(x.shape[0]) if num_peds is None else int((torch.as_tensor(num_peds) > 0).sum())
             mom = model.st_gcns[0].tcn[0].momentum
-            for b, b0 in zip(self._bn_buffers(), before):
-                b.copy_(fold_bn_across_ranks(b0, b.detach(), n_local, mom, self.group))
+            flat_b = model._pb.flat
+            flat_b.copy_(fold_bn_across_ranks(before, flat_b.clone(), n_local, mom, self.group))
         if self.clip_grad is not None:
             torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], self.clip_grad)
             flat_g = self._flat_grad()
@@ -127,42 +140,70 @@ class Trainer:
 
     # ---- hipGraph capture of the step (launch-bound at these sizes: ~15 kernels of 10-150 us) ----------
     def capture(self, x, adj, target, num_peds=None, weights=None, warmup=3):
-        """Capture forward + loss + backward (+ SGD update when single-rank) into ONE hipGraph on static
-        input tensors and return `replay()`.  x / adj / target / num_peds / weights must be device tensors
-        that stay alive; refresh their contents in place between replays.  With several ranks the graph
-        holds forward+backward and the gradient all-reduce, BatchNorm fold and SGD run eagerly after it."""
+        """Capture the training step on static input tensors and return `replay()`.
+
+        Single rank: ONE hipGraph = forward + loss + backward + SGD update.
+        Several ranks: graph A = snapshot of the BatchNorm statistics + forward + loss + backward + packing of
+        [gradient | this rank's scaled BatchNorm contribution] into one flat buffer; then ONE eager all-reduce
+        (RCCL) of that 7,593-float buffer; graph B = BatchNorm fold + SGD update.  Every rank must hold the same
+        number of scenes (x.shape[0]).  x / adj / target / num_peds / weights must be device tensors that stay
+        alive; refresh their contents in place between replays."""
         if num_peds is not None and not (torch.is_tensor(num_peds) and num_peds.is_cuda):
             raise ValueError("capture() needs num_peds as a device tensor (no host->device copies in a graph)")
         single = self.world == 1
+        model = self.model
+        # warm-up launches (outside the capture) must not change the model: snapshot / restore its state
+        flat_p = model.flat_parameters()
+        flat_b = model._pb.ensure(self._bn_buffers())
+        nbt = model._tensors()[2]
+        saved = (flat_p.clone(), flat_b.clone(), [t.clone() for t in nbt])
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
+            for _ in range(max(1, warmup)):
                 if single:
                     self.step(x, adj, target, num_peds, weights)
                 else:
                     self.forward_backward(x, adj, target, num_peds, weights)
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = self.step(x, adj, target, num_peds, weights) if single else \
-                self.forward_backward(x, adj, target, num_peds, weights)
-        model = self.model
+        with torch.no_grad():
+            flat_p.copy_(saved[0])
+            flat_b.copy_(saved[1])
+            for t, t0 in zip(nbt, saved[2]):
+                t.copy_(t0)
+        if single:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.step(x, adj, target, num_peds, weights)
+            self._graph = graph
 
-        def replay():
-            if single:
+            def replay():
                 graph.replay()
                 return out
-            before = model._pb.flat.clone()
-            graph.replay()
-            flat_g = self._flat_grad()
-            allreduce_flat(flat_g, self.group)
-            n_local = int(x.shape[0])
-            mom = model.st_gcns[0].tcn[0].momentum
-            model._pb.flat.copy_(fold_bn_across_ranks(before, model._pb.flat, n_local, mom, self.group))
-            ops.sgd_step(model.flat_parameters(), flat_g, self.lr)
+            return replay
+
+        n_p, n_b = flat_p.numel(), flat_b.numel()
+        rank = dist.get_rank(self.group)
+        own, later, total = bn_fold_scale([int(x.shape[0])] * self.world, rank, model.st_gcns[0].tcn[0].momentum)
+        pack = torch.zeros(n_p + n_b, device=flat_p.device, dtype=torch.float32)
+        before = torch.empty_like(flat_b)
+        g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_a):
+            before.copy_(flat_b)
+            out = self.forward_backward(x, adj, target, num_peds, weights)
+            pack[:n_p].copy_(self._flat_grad())
+            torch.sub(flat_b, before, alpha=own, out=pack[n_p:])
+            pack[n_p:].mul_(later)
+        with torch.cuda.graph(g_b, pool=g_a.pool()):
+            torch.add(pack[n_p:], before, alpha=total, out=flat_b)
+            ops.sgd_step(flat_p, pack[:n_p], self.lr)
+        self._graph = (g_a, g_b)
+
+        def replay():
+            g_a.replay()
+            dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=self.group)      # the step's ONE collective
+            g_b.replay()
             return out
-        self._graph = graph
         return replay
 
     def _flat_grad(self):
