@@ -33,7 +33,7 @@ extern "C" {
 #define STG_EUNSUPPORTED (-2) /* configuration outside what the kernels are built for      */
 #define STG_ELDS (-3)        /* scene too large for the 160 KiB LDS of one CU             */
 
-#define STG_ABI_VERSION 2
+#define STG_ABI_VERSION 3
 #define STG_MAX_BLOCKS 4     /* st_gcn blocks in one fused model                          */
 
 int stg_abi_version(void);
@@ -151,10 +151,12 @@ int stg_bn_fold(const stg_model_desc *d, const float *stats, const int32_t *num_
  * R6  metrics.bivariate_loss (metrics.py:84-113), batched: loss[n] = mean over (P, V_n) of
  *     -log(clamp(pdf, 1e-20)).  pred element (n,f,p,v) at pred[n*p_sn + f*p_sf + p*p_sp + v*p_sv]
  *     (f = mux,muy,log sx,log sy,atanh rho; the model output (N,5,P,V) is p_sf=P*V, p_sp=V, p_sv=1);
- *     target (N,P,V,2) contiguous.  grad (N,5,P,V) contiguous receives d loss[n] / d pred (may be NULL).
+ *     target (N,P,V,2) contiguous.  grad (N,5,P,V) contiguous receives grad_scale[n] * d loss[n] / d pred
+ *     (grad may be NULL; grad_scale float[N] may be NULL = 1: the caller's per-scene loss weights, so that
+ *     grad is directly d(sum_n w_n loss_n)/d pred).
  */
 int stg_nll_fwd(const float *pred, int64_t p_sn, int64_t p_sf, int64_t p_sp, int64_t p_sv,
-                const float *target, const int32_t *num_peds, int N, int P, int V,
+                const float *target, const int32_t *num_peds, const float *grad_scale, int N, int P, int V,
                 float *loss, float *grad, void *stream);
 /* out[n,f,p,v] = grad[n,f,p,v] * gloss[n]  (chain rule with the upstream gradient of loss[n]). */
 int stg_nll_bwd(const float *grad, const float *gloss, int N, int P, int V, float *out, void *stream);

@@ -55,6 +55,12 @@ struct WgradArgs {
 };
 
 // slab geometry of K2: layer 0 has c_in = T, layers 1..L (L = output conv) have c_in = P
+// floats of one wave-private LDS image of K2: a staged scene (plane + dz), and at the end one slab row
+__host__ __device__ inline int wgrad_image_floats(int V) {
+    const int img = plane_slot(V) + dz_slot(V);
+    const int row = (Cfg::P * Cfg::P * 9 + Cfg::P + 3) & ~3;
+    return img > row ? img : row;
+}
 __host__ __device__ inline int wgrad_row_len(int layer) {
     return Cfg::P * (layer == 0 ? Cfg::T : Cfg::P) * 9 + Cfg::P;
 }
@@ -784,8 +790,9 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
         }
         __builtin_amdgcn_wave_barrier();
     }
-    // one slab row per wave: [P][CINL][9] weights then [P] biases (the parameters' own order)
-    float *row = a.slab2 + wgrad_slab_base(layer, a.rows) + (int64_t)row_id * wgrad_row_len(layer);
+    // each wave parks its accumulator tiles in its own LDS image as one row [P][CINL][9] weights + [P] biases
+    // (the parameters' own order); the workgroup then sums its waves' rows into ONE slab row
+    float *row = buf0;
     if (kq < 3) {
 #pragma unroll
         for (int tl = 0; tl < NTILE; ++tl) {
@@ -810,17 +817,28 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void txp_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int wave = threadIdx.x >> 6;
-    const int image = plane_slot(a.V) + dz_slot(a.V);          // one staged scene: plane + dz
+    const int image = wgrad_image_floats(a.V);                 // one staged scene (plane + dz), >= one slab row
     float *buf0 = sm + wave * image, *buf1 = buf0;
     // blockIdx.x -> (layer, workgroup within the layer): layer l owns blocks [wg_begin[l], wg_begin[l+1])
     int layer = 0;
     while (layer < a.lay.L && (int)blockIdx.x >= a.wg_begin[layer + 1]) ++layer;
-    const int row_id = ((int)blockIdx.x - a.wg_begin[layer]) * WAVES + wave;      // slab row of this wave
+    const int wg = (int)blockIdx.x - a.wg_begin[layer];
+    const int row_id = wg * WAVES + wave;                                           // this wave's scene lane
     const int nrows = (a.wg_begin[layer + 1] - a.wg_begin[layer]) * WAVES;          // waves of this layer
     if (layer == 0)
         wgrad_layer<Cfg::T>(a, layer, buf0, buf1, row_id, nrows);
     else
         wgrad_layer<Cfg::P>(a, layer, buf0, buf1, row_id, nrows);
+    __syncthreads();
+    // slab row of the workgroup = sum of its waves' rows, fixed order
+    const int len = wgrad_row_len(layer);
+    float *dst = a.slab2 + wgrad_slab_base(layer, a.rows) + (int64_t)wg * len;
+    for (int e = threadIdx.x; e < len; e += WAVES * 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < WAVES; ++w2) t += sm[w2 * image + e];
+        dst[e] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -923,7 +941,7 @@ struct WgradGeom {
     size_t lds;
 };
 static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
-    const size_t per_wave = (size_t)(plane_slot(V) + dz_slot(V)) * sizeof(float);
+    const size_t per_wave = (size_t)wgrad_image_floats(V) * sizeof(float);
     if (per_wave > (size_t)kLdsBytes) return false;
     int waves = env_waves("STG_WGRAD_WAVES", 4);
     while (waves > 1 && per_wave * waves > (size_t)kLdsBytes) waves >>= 1;
@@ -952,7 +970,7 @@ static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
     }
     g->wg_begin[nl] = begin;
     g->grid = begin;
-    g->rows = maxw * waves;
+    g->rows = maxw;                                    // one slab row per workgroup
     return true;
 }
 

@@ -9,8 +9,8 @@ namespace stg {
 
 __global__ __launch_bounds__(256) void nll_fwd_kernel(
     const float *__restrict__ pred, int64_t p_sn, int64_t p_sf, int64_t p_sp, int64_t p_sv,
-    const float *__restrict__ target, const int32_t *__restrict__ num_peds, int P, int V,
-    float *__restrict__ loss, float *__restrict__ grad) {
+    const float *__restrict__ target, const int32_t *__restrict__ num_peds, const float *__restrict__ gscale,
+    int P, int V, float *__restrict__ loss, float *__restrict__ grad) {
     __shared__ float red[4];
     const int n = blockIdx.x, tid = threadIdx.x;
     int vi = num_peds ? num_peds[n] : V;
@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void nll_fwd_kernel(
     const float *tn = target + (int64_t)n * P * V * 2;
     float *gn = grad ? grad + (int64_t)n * 5 * P * V : nullptr;
     const float inv_cnt = vi > 0 ? 1.0f / (float)(P * vi) : 0.f;
+    const float gs = inv_cnt * (gscale ? gscale[n] : 1.f);      // d(mean)/d(elem) times the caller's per-scene weight
     float acc = 0.f;
     for (int e = tid; e < P * V; e += blockDim.x) {
         const int p = e / V, v = e - p * V;
@@ -50,11 +51,11 @@ __global__ __launch_bounds__(256) void nll_fwd_kernel(
         }
         if (gn) {
             const int64_t pv = (int64_t)P * V;
-            gn[e] = g0 * inv_cnt;
-            gn[pv + e] = g1 * inv_cnt;
-            gn[2 * pv + e] = g2 * inv_cnt;
-            gn[3 * pv + e] = g3 * inv_cnt;
-            gn[4 * pv + e] = g4 * inv_cnt;
+            gn[e] = g0 * gs;
+            gn[pv + e] = g1 * gs;
+            gn[2 * pv + e] = g2 * gs;
+            gn[3 * pv + e] = g3 * gs;
+            gn[4 * pv + e] = g4 * gs;
         }
     }
     acc = wave_sum(acc);
@@ -63,8 +64,8 @@ __global__ __launch_bounds__(256) void nll_fwd_kernel(
     if (tid == 0) loss[n] = (red[0] + red[1] + red[2] + red[3]) * inv_cnt;
 }
 
-__global__ void nll_bwd_kernel(const float *__restrict__ grad, const float *__restrict__ gloss, int64_t per_scene,
-                               int64_t total, float *__restrict__ out) {
+__global__ void nll_bwd_kernel(const float *grad, const float *__restrict__ gloss, int64_t per_scene,
+                               int64_t total, float *out) {      // out may alias grad
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < total) out[i] = grad[i] * gloss[i / per_scene];
 }
@@ -74,12 +75,13 @@ __global__ void nll_bwd_kernel(const float *__restrict__ grad, const float *__re
 extern "C" {
 
 int stg_nll_fwd(const float *pred, int64_t p_sn, int64_t p_sf, int64_t p_sp, int64_t p_sv, const float *target,
-                const int32_t *num_peds, int N, int P, int V, float *loss, float *grad, void *stream) {
+                const int32_t *num_peds, const float *grad_scale, int N, int P, int V, float *loss, float *grad,
+                void *stream) {
     STG_REQUIRE(pred && target && loss, STG_EINVAL, "stg_nll_fwd: null pointer");
     STG_REQUIRE(N >= 0 && P > 0 && V > 0, STG_EINVAL, "stg_nll_fwd: bad sizes N=%d P=%d V=%d", N, P, V);
     if (N == 0) return STG_OK;
     hipLaunchKernelGGL(stg::nll_fwd_kernel, dim3(N), dim3(256), 0, stg::as_stream(stream), pred, p_sn, p_sf, p_sp,
-                       p_sv, target, num_peds, P, V, loss, grad);
+                       p_sv, target, num_peds, grad_scale, P, V, loss, grad);
     STG_LAUNCH_CHECK("stg_nll_fwd");
     return STG_OK;
 }

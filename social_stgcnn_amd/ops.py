@@ -318,7 +318,7 @@ class _BivariateNLL(torch.autograd.Function):
         need = ctx.needs_input_grad[0]
         grad = torch.empty((n, 5, p, v), device=pred.device, dtype=torch.float32) if need else None
         sn, sp, sv, sf = pred.stride()
-        check(lib().stg_nll_fwd(ptr(pred), sn, sf, sp, sv, ptr(target), ptr(peds), n, p, v, ptr(loss), ptr(grad),
+        check(lib().stg_nll_fwd(ptr(pred), sn, sf, sp, sv, ptr(target), ptr(peds), None, n, p, v, ptr(loss), ptr(grad),
                                 stream_ptr()), "stg_nll_fwd")
         ctx.grad = grad
         return loss
@@ -336,6 +336,24 @@ class _BivariateNLL(torch.autograd.Function):
 
 def bivariate_nll(pred, target, num_peds=None):
     return _BivariateNLL.apply(pred, target, num_peds)
+
+
+def bivariate_nll_with_grad(y, target, num_peds=None, weights=None):
+    """Trainer fast path: y (N,5,P,V) model output (contiguous), target (N,P,V,2) ->
+    (per-scene losses (N,), d(sum_n w_n loss_n)/dy (N,5,P,V)) from ONE nll_fwd launch."""
+    require_gpu(y, target)
+    n, f, p, v = y.shape
+    if f != 5 or tuple(target.shape) != (n, p, v, 2):
+        raise ValueError("bivariate_nll_with_grad: y (N,5,P,V) / target (N,P,V,2) expected")
+    target = target.to(torch.float32).contiguous()
+    peds = peds_arg(num_peds, n, y.device)
+    loss = torch.empty(n, device=y.device, dtype=torch.float32)
+    grad = torch.empty((n, 5, p, v), device=y.device, dtype=torch.float32)
+    w = weights.to(torch.float32).contiguous() if weights is not None else None
+    sn, sf, sp, sv = y.stride()
+    check(lib().stg_nll_fwd(ptr(y), sn, sf, sp, sv, ptr(target), ptr(peds), ptr(w), n, p, v, ptr(loss), ptr(grad),
+                            stream_ptr()), "stg_nll_fwd")
+    return loss, grad
 
 
 def sgd_step(flat_params, flat_grads, lr):

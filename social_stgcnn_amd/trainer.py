@@ -111,10 +111,12 @@ class Trainer:
         for p in model.parameters():
             p.grad = None
         y, _ = model(x, adj, num_peds)
-        losses = bivariate_loss(y.permute(0, 2, 3, 1), target, num_peds)
-        total = losses.sum() if weights is None else (losses * weights).sum()
-        total.backward()
-        return total.detach(), losses.detach(), y.detach()
+        # loss + its gradient w.r.t. V_pred in ONE kernel (per-scene weights folded in), then backward straight
+        # from dV_pred: no autograd graph through the loss, no separate scale / sum / expand kernels
+        losses, dy = ops.bivariate_nll_with_grad(y.detach(), target, num_peds, weights)
+        y.backward(dy)
+        total = losses.sum() if weights is None else torch.dot(losses, weights)
+        return total, losses, y.detach()
 
     def step(self, x, adj, target, num_peds=None, weights=None):
         """forward_backward + gradient all-reduce + BatchNorm fold across ranks + SGD update."""
