@@ -856,28 +856,27 @@ struct ReduceArgs {
     int n_params;
 };
 
-// One workgroup owns 32 consecutive parameters (one 128-byte line per slab row); its 8 lane-groups
-// stride over the rows, partial sums meet in LDS in a fixed order.
+// One workgroup owns 8 consecutive parameters; its 32 lane-groups stride over the slab rows (up to 2048 of
+// them), 4 independent row loads in flight each; the 32 partial sums meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceArgs a) {
-    __shared__ float part[8][32];
-    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int p = blockIdx.x * 32 + col;
+    __shared__ float part[32][8];
+    const int col = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const int p = blockIdx.x * 8 + col;
     float s = 0.f;
     if (p < a.n_params) {
         for (int q = 0; q < a.n_seg; ++q) {
             const ReduceSeg g = a.seg[q];
             if (p >= g.p0 && p < g.p0 + g.len) {
                 const float *src = a.slabs + g.base + (p - g.p0);
-                // 8 independent row loads in flight; the summation order is fixed (deterministic)
                 int k = grp;
-                for (; k + 56 < g.rows; k += 64) {
-                    float v[8];
+                for (; k + 96 < g.rows; k += 128) {
+                    float v[4];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + 8 * u) * g.row_stride];
+                    for (int u = 0; u < 4; ++u) v[u] = src[(int64_t)(k + 32 * u) * g.row_stride];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) s += v[u];
+                    for (int u = 0; u < 4; ++u) s += v[u];
                 }
-                for (; k < g.rows; k += 8) s += src[(int64_t)k * g.row_stride];
+                for (; k < g.rows; k += 32) s += src[(int64_t)k * g.row_stride];
             }
         }
     }
@@ -886,7 +885,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceArgs a) {
     if (grp == 0 && p < a.n_params) {
         float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) t += part[g][col];
+        for (int g = 0; g < 32; ++g) t += part[g][col];
         a.grad[p] = t;
     }
 }
@@ -1139,7 +1138,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
                                          s2 + wgrad_slab_base(l, wg.rows)};
         }
     }
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((L.n_params + 31) / 32), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((L.n_params + 7) / 8), dim3(256), 0, st, r);
     STG_LAUNCH_CHECK("stg_model_bwd: reduce_slabs");
     return STG_OK;
 }
