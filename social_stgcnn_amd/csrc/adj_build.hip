@@ -118,10 +118,10 @@ __global__ __launch_bounds__(256) void adj_build_kernel(
 extern "C" int stg_adj_build(const float *rel, int64_t rel_sn, int64_t rel_sv, int64_t rel_sc,
                              int64_t rel_st, const int32_t *num_peds, int N, int V, int T,
                              int normalize, float *nodes, float *adj, void *stream) {
-    STG_REQUIRE(rel && adj, STG_EINVAL, "stg_adj_build: null rel/adj pointer");
     STG_REQUIRE(N >= 0 && V > 0 && T > 0, STG_EINVAL, "stg_adj_build: bad sizes N=%d V=%d T=%d", N, V, T);
     STG_REQUIRE((int64_t)N * T < (1ll << 31), STG_EINVAL, "stg_adj_build: N*T too large");
     if (N == 0) return STG_OK;
+    STG_REQUIRE(rel && adj, STG_EINVAL, "stg_adj_build: null rel/adj pointer");
     const size_t lds = (size_t)4 * T * V * sizeof(float);
     STG_REQUIRE(lds <= stg::kLdsBytes, STG_ELDS, "stg_adj_build: V=%d exceeds the LDS budget", V);
     const dim3 grid((unsigned)N), block(256);

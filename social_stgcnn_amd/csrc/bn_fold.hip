@@ -57,8 +57,9 @@ extern "C" int stg_bn_fold(const stg_model_desc *d, const float *stats, const in
     ModelLayout l;
     const int rc = make_layout(d, &l);
     if (rc != STG_OK) return rc;
-    STG_REQUIRE(stats && buffers, STG_EINVAL, "stg_bn_fold: null pointer");
     STG_REQUIRE(N >= 0, STG_EINVAL, "stg_bn_fold: N=%d", N);
+    if (N == 0) return STG_OK;
+    STG_REQUIRE(stats && buffers, STG_EINVAL, "stg_bn_fold: null pointer");
     STG_REQUIRE(n_bn >= 0 && n_bn <= 3 * STG_MAX_BLOCKS, STG_EINVAL, "stg_bn_fold: n_bn=%d", n_bn);
     STG_REQUIRE(n_bn <= l.n_buffers, STG_EINVAL, "stg_bn_fold: n_bn=%d > statistics %d", n_bn, l.n_buffers);
     if (N == 0 || l.n_buffers == 0) return STG_OK;

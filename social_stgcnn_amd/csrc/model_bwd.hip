@@ -1022,9 +1022,10 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     const int rc = make_layout(d, &a.lay);
     if (rc != STG_OK) return rc;
     const ModelLayout &L = a.lay;
-    STG_REQUIRE(params && buffers && x && adj && dy && ws && scratch && grad_params, STG_EINVAL,
-                "stg_model_bwd: null pointer");
     STG_REQUIRE(N >= 0 && V > 0, STG_EINVAL, "stg_model_bwd: bad sizes N=%d V=%d", N, V);
+    STG_REQUIRE(grad_params, STG_EINVAL, "stg_model_bwd: null grad_params");
+    STG_REQUIRE(N == 0 || (params && buffers && x && adj && dy && ws && scratch), STG_EINVAL,
+                "stg_model_bwd: null pointer");
     STG_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0,
                 STG_EINVAL, "stg_model_bwd: ws / scratch must be 16-byte aligned");
     hipStream_t st = as_stream(stream);

@@ -516,8 +516,9 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     FwdArgs a{};
     const int rc = make_layout(d, &a.lay);
     if (rc != STG_OK) return rc;
-    STG_REQUIRE(params && buffers && x && adj && y, STG_EINVAL, "stg_model_fwd: null pointer");
     STG_REQUIRE(N >= 0 && V > 0, STG_EINVAL, "stg_model_fwd: bad sizes N=%d V=%d", N, V);
+    if (N == 0) return STG_OK;                        // empty batch: nothing to read or write
+    STG_REQUIRE(params && buffers && x && adj && y, STG_EINVAL, "stg_model_fwd: null pointer");
     if (N == 0) return STG_OK;
     a.params = params; a.buffers = buffers; a.x = x;
     a.x_sn = x_sn; a.x_sc = x_sc; a.x_st = x_st; a.x_sv = x_sv;

@@ -77,9 +77,9 @@ extern "C" {
 int stg_nll_fwd(const float *pred, int64_t p_sn, int64_t p_sf, int64_t p_sp, int64_t p_sv, const float *target,
                 const int32_t *num_peds, const float *grad_scale, int N, int P, int V, float *loss, float *grad,
                 void *stream) {
-    STG_REQUIRE(pred && target && loss, STG_EINVAL, "stg_nll_fwd: null pointer");
     STG_REQUIRE(N >= 0 && P > 0 && V > 0, STG_EINVAL, "stg_nll_fwd: bad sizes N=%d P=%d V=%d", N, P, V);
     if (N == 0) return STG_OK;
+    STG_REQUIRE(pred && target && loss, STG_EINVAL, "stg_nll_fwd: null pointer");
     hipLaunchKernelGGL(stg::nll_fwd_kernel, dim3(N), dim3(256), 0, stg::as_stream(stream), pred, p_sn, p_sf, p_sp,
                        p_sv, target, num_peds, grad_scale, P, V, loss, grad);
     STG_LAUNCH_CHECK("stg_nll_fwd");

@@ -516,3 +516,63 @@ def test_inference_matches_training_forward(dev):
     for i, v in enumerate(vs):
         assert _maxdiff(y[i, :, :, :v].cpu().numpy(), f["vpred_%d" % v][0]) < 2e-5, v
         assert torch.all(y[i, :, :, v:] == 0)
+
+
+def test_empty_and_degenerate_batches(dev):
+    """Edge cases: an empty batch, scenes with zero pedestrians inside a batch, and single-pedestrian scenes
+    (the reference's dataset never emits V=1 windows -- utils.py:171 keeps windows with >1 pedestrians -- but the
+    kernels must not misbehave on them)."""
+    from social_stgcnn_amd import ops
+    from social_stgcnn_amd.metrics import bivariate_loss
+    O = _oracle()
+    m = _model(dev, seed=5).train()
+    state0 = {k: val.detach().cpu().clone() for k, val in m.state_dict().items()}
+    # N = 0
+    y, _ = m(torch.zeros(0, 2, 8, 4, device=dev), torch.zeros(0, 8, 4, 4, device=dev))
+    assert y.shape == (0, 5, 12, 4)
+    nodes, adj = ops.adj_build(torch.zeros(0, 4, 2, 8, device=dev))
+    assert adj.shape == (0, 8, 4, 4)
+    for k, val in m.state_dict().items():
+        assert torch.equal(val.cpu(), state0[k]), k                      # nothing moved
+    # zero-ped scenes inside a batch: skipped everywhere (outputs 0, no BatchNorm update, no gradient)
+    a = load_golden("adj_cases.npz")
+    vs = [0, 5, 0, 1, 3]
+    vmax = 5
+    rel = torch.zeros(len(vs), vmax, 2, 20)
+    g = torch.Generator().manual_seed(2)
+    for i, v in enumerate(vs):
+        rel[i, :v, :, 1:] = (torch.rand(v, 2, 19, generator=g) - 0.5).mul(1e4).round().div(1e4)
+    rel_d = rel.to(dev)
+    peds = torch.tensor(vs, dtype=torch.int32, device=dev)
+    nodes, adj = ops.adj_build(rel_d[..., :8], peds)
+    tgt = rel_d[..., 8:].permute(0, 3, 1, 2).contiguous()
+    y, _ = m(nodes.permute(0, 3, 1, 2), adj, peds)
+    losses = bivariate_loss(y.permute(0, 2, 3, 1), tgt, peds)
+    losses.sum().backward()
+    assert torch.all(y[0] == 0) and torch.all(y[2] == 0) and float(losses[0]) == 0 and float(losses[2]) == 0
+    # oracle on the three non-empty scenes (V = 5, 1, 3)
+    keys = [k for k, _ in m.named_parameters()]
+    params = {k: state0[k].clone().requires_grad_(True) for k in keys}
+    work = dict(state0)
+    work.update(params)
+    tot = 0
+    for i, v in enumerate(vs):
+        if v == 0:
+            continue
+        n_i, l_i = O.seq_to_graph_np(rel[i, :v, :, :8].numpy())
+        t_i, _ = O.seq_to_graph_np(rel[i, :v, :, 8:].numpy())
+        l, vp = O.scene_loss(work, torch.from_numpy(n_i).unsqueeze(0).permute(0, 3, 1, 2), torch.from_numpy(l_i),
+                             torch.from_numpy(t_i), True)
+        tot = tot + l
+        assert _maxdiff(y[i, :, :, :v].detach().permute(1, 2, 0).cpu().numpy(), vp.detach().numpy()) < 2e-5, i
+        assert abs(float(losses[i]) - float(l)) < 2e-5
+    tot.backward()
+    errs = _grad_errors(((name, p.grad) for name, p in m.named_parameters()),
+                        lambda name: None if params[name].grad is None else params[name].grad.numpy())
+    bad = {k: e for k, e in errs.items() if e > 2e-4}
+    assert not bad, bad
+    for k, val in m.state_dict().items():
+        if "running" in k:
+            assert _maxdiff(val.cpu().numpy(), work[k].numpy()) < 2e-6, k
+        if "num_batches" in k:
+            assert int(val) == 3, k                                         # only the non-empty scenes count
