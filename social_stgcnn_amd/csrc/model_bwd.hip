@@ -49,7 +49,6 @@ struct WgradArgs {
     int64_t ws_stride;
     float *slab2;          // [layer 0..L][rows][row_len(layer)] packed, see wgrad_slab_base()
     int rows;              // slab rows per layer = gridDim.x * WAVES
-    int *counters;         // [L+1] scene queue heads, one per layer (zeroed by the launcher)
     int wg_begin[kMaxTxp + 2];   // workgroup ranges per layer: layer l owns blocks [wg_begin[l], wg_begin[l+1])
     int debug_skip;        // timing-only diagnostic: 64 skip staging, 128 skip the MFMA loop
 };
@@ -704,8 +703,7 @@ __device__ __forceinline__ int wgrad_vi(const WgradArgs &a, int n) {
 }
 
 template <int CINL>
-__device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float *buf0, float *buf1, int row_id,
-                                            int nrows) {
+__device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float *buf0, int row_id, int nrows) {
     constexpr int C = Cfg::C, P = Cfg::P;
     constexpr int NCOL = 9 * CINL + 1, NTILE = (NCOL + 15) / 16;
     const int V = a.V, lane = threadIdx.x & 63;
@@ -729,7 +727,6 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
     // images per wave halve the residency to one wave per SIMD, and this loop needs two to hide its LDS
     // latency (measured slower, profiles/); a device-scope scene queue was slower too (dequeue latency).
     float *cur = buf0;
-    (void)buf1;
     for (int n = __builtin_amdgcn_readfirstlane(row_id); n < a.N; n += nrows) {
         const int vi = wgrad_vi(a, n);
         if (vi == 0) continue;
@@ -818,7 +815,7 @@ __global__ __launch_bounds__(WAVES * 64) void txp_wgrad_kernel(const WgradArgs a
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int wave = threadIdx.x >> 6;
     const int image = wgrad_image_floats(a.V);                 // one staged scene (plane + dz), >= one slab row
-    float *buf0 = sm + wave * image, *buf1 = buf0;
+    float *buf0 = sm + wave * image;
     // blockIdx.x -> (layer, workgroup within the layer): layer l owns blocks [wg_begin[l], wg_begin[l+1])
     int layer = 0;
     while (layer < a.lay.L && (int)blockIdx.x >= a.wg_begin[layer + 1]) ++layer;
@@ -826,9 +823,9 @@ __global__ __launch_bounds__(WAVES * 64) void txp_wgrad_kernel(const WgradArgs a
     const int row_id = wg * WAVES + wave;                                           // this wave's scene lane
     const int nrows = (a.wg_begin[layer + 1] - a.wg_begin[layer]) * WAVES;          // waves of this layer
     if (layer == 0)
-        wgrad_layer<Cfg::T>(a, layer, buf0, buf1, row_id, nrows);
+        wgrad_layer<Cfg::T>(a, layer, buf0, row_id, nrows);
     else
-        wgrad_layer<Cfg::P>(a, layer, buf0, buf1, row_id, nrows);
+        wgrad_layer<Cfg::P>(a, layer, buf0, row_id, nrows);
     __syncthreads();
     // slab row of the workgroup = sum of its waves' rows, fixed order
     const int len = wgrad_row_len(layer);
@@ -988,7 +985,6 @@ static int64_t bwd_scratch_floats(const ModelLayout &L, int N, int V) {
         fl += wgrad_slab_base(L.L + 1, g.rows);
         fl = (fl + 3) & ~(int64_t)3;
         fl += (int64_t)N * L.L * dz_slot(V);
-        fl += 16;                                                // K2 scene-queue heads (one int per layer)
         if (txp_wave_fits(L, V)) {
             fl += (int64_t)N * (Cfg::C * Cfg::T * V);            // d(a_0) hand-off
             fl = (fl + 3) & ~(int64_t)3;
@@ -1047,15 +1043,12 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     float *slab2 = scratch + off;
     WgradGeom wg{};
     float *dzg = nullptr;
-    int *k2_counters = nullptr;
     if (L.n_txp > 0) {
         STG_REQUIRE(wgrad_geom(L, N, V, &wg), STG_ELDS, "stg_model_bwd: V=%d does not fit LDS (wgrad)", V);
         off += wgrad_slab_base(L.L + 1, wg.rows);
         off = (off + 3) & ~(int64_t)3;
         dzg = scratch + off;
         off += (int64_t)N * L.L * dz_slot(V);
-        k2_counters = reinterpret_cast<int *>(scratch + off);
-        off += 16;
     }
     const bool wave_path = txp_wave_fits(L, V);
     float *da0 = nullptr, *slopes = nullptr;
@@ -1109,7 +1102,6 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         WgradArgs w{};
         w.lay = L; w.num_peds = num_peds; w.N = N; w.V = V; w.dy = dy; w.ws = ws; w.dzg = dzg;
         w.ws_stride = a.ws_stride; w.slab2 = slab2; w.rows = wg.rows; w.debug_skip = a.debug_skip;
-        w.counters = k2_counters;
         for (int l = 0; l <= L.L + 1; ++l) w.wg_begin[l] = wg.wg_begin[l];
         if (!(a.debug_skip & 1)) {
             // unused slab rows (layers with fewer workgroups than `rows`) must read as zero
