@@ -166,13 +166,13 @@ __device__ void txp_dgrad(const float *__restrict__ W, const float *dzb, float *
 // ([CIN][T][vi], LDS; may alias D) -- needed for stacked blocks; `dxg` is the optional global dx.
 // ------------------------------------------------------------------------------------------
 template <int CIN, int WAVES>
-__device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, int vi, float *D, float *H1,
+__device__ void stgcn_block_bwd(const BwdArgs &a, const float *P_, const BlockLayout &b, int n, int vi,
+                                float *D, float *H1,
                                 float *DH2, float *DB1, float *red, float *tot, float *gsm, const float *wsn,
                                 const float *xin_ws /* block input saved by the previous block, or null */,
                                 float *dxs, float *dxg, const float *lds_saved /* staged [ax|cs|g|h2] or null */) {
     constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, NT = WAVES * 64, TP = T + 2;
     const int tid = threadIdx.x, V = a.V, cnt = T * vi;
-    const float *P_ = a.params;
     const bool train = a.lay.bn_mode == 1;
     const float inv_cnt = 1.0f / (float)cnt;
     const float *wsa = wsn + a.lay.ws_hdr_floats;     // saved arrays sit behind the header
@@ -203,6 +203,18 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
 #pragma unroll
         for (int k = 0; k < 3 * C + 1; ++k) s[k] = 0.f;
         const float ao = P_[b.prelu_o], a1 = P_[b.prelu1];
+        // loop-invariant parameters into registers once per pass (the compiler cannot hoist them itself:
+        // params may alias the kernel's stores)
+        float g2[C], b2[C], gr[C], br[C], g1[C], b1p[C], rb[C], rw[C * CIN];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            g2[c] = P_[b.bn2_g + c]; b2[c] = P_[b.bn2_b + c]; g1[c] = P_[b.bn1_g + c]; b1p[c] = P_[b.bn1_b + c];
+            gr[c] = b.residual == 2 ? P_[b.bnr_g + c] : 0.f;
+            br[c] = b.residual == 2 ? P_[b.bnr_b + c] : 0.f;
+            rb[c] = b.residual == 2 ? P_[b.res_b + c] : 0.f;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) rw[c * CIN + ci] = b.residual == 2 ? P_[b.res_w + c * CIN + ci] : 0.f;
+        }
         // zero rows of the t-padded h1 plane
         for (int e = tid; e < C * vi; e += NT) {
             const int c = e / vi, w = e - c * vi;
@@ -220,14 +232,14 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
             for (int c = 0; c < C; ++c) {
                 const int i = (c * T + t) * vi + w;
                 const float x2 = (w_h2[i] - m2[c]) * r2[c];
-                float u = fmaf(x2, P_[b.bn2_g + c], P_[b.bn2_b + c]);
+                float u = fmaf(x2, g2[c], b2[c]);
                 float xr = 0.f;
                 if (b.residual == 2) {
-                    float r = P_[b.res_b + c];
+                    float r = rb[c];
 #pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) r = fmaf(P_[b.res_w + c * CIN + ci], xv[ci], r);
+                    for (int ci = 0; ci < CIN; ++ci) r = fmaf(rw[c * CIN + ci], xv[ci], r);
                     xr = (r - mr[c]) * rr[c];
-                    u += fmaf(xr, P_[b.bnr_g + c], P_[b.bnr_b + c]);
+                    u += fmaf(xr, gr[c], br[c]);
                 } else if (b.residual == 1) {
                     if (CIN == C) u += xv[c % CIN];
                 }
@@ -242,7 +254,7 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
                 s[C + c] = fmaf(du, x2, s[C + c]);
                 s[2 * C + c] = fmaf(du, xr, s[2 * C + c]);
                 // h1 for the temporal-conv weight gradient
-                const float b1 = fmaf((w_g[i] - m1[c]) * r1[c], P_[b.bn1_g + c], P_[b.bn1_b + c]);
+                const float b1 = fmaf((w_g[i] - m1[c]) * r1[c], g1[c], b1p[c]);
                 H1[(c * TP + t + 1) * vi + w] = b1 > 0.f ? b1 : a1 * b1;
             }
         }
@@ -274,6 +286,15 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
         float s[K2];
 #pragma unroll
         for (int k = 0; k < K2; ++k) s[k] = 0.f;
+        float g2[C], gr[C], rb[C], rw[C * CIN];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            g2[c] = P_[b.bn2_g + c];
+            gr[c] = b.residual == 2 ? P_[b.bnr_g + c] : 0.f;
+            rb[c] = b.residual == 2 ? P_[b.res_b + c] : 0.f;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) rw[c * CIN + ci] = b.residual == 2 ? P_[b.res_w + c * CIN + ci] : 0.f;
+        }
         for (int q = tid; q < cnt; q += NT) {
             const int t = q / vi, w = q - t * vi;
             float xv[CIN];
@@ -286,13 +307,13 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
                 const int i = (c * T + t) * vi + w;
                 const float du = D[i];
                 const float x2 = (w_h2[i] - m2[c]) * r2[c];
-                DH2[(c * TP + t + 1) * vi + w] = P_[b.bn2_g + c] * r2[c] * (du - mdu[c] - x2 * mdx2[c]);
+                DH2[(c * TP + t + 1) * vi + w] = g2[c] * r2[c] * (du - mdu[c] - x2 * mdx2[c]);
                 if (b.residual == 2) {
-                    float r = P_[b.res_b + c];
+                    float r = rb[c];
 #pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) r = fmaf(P_[b.res_w + c * CIN + ci], xv[ci], r);
+                    for (int ci = 0; ci < CIN; ++ci) r = fmaf(rw[c * CIN + ci], xv[ci], r);
                     const float xr = (r - mr[c]) * rr[c];
-                    const float dr = P_[b.bnr_g + c] * rr[c] * (du - mdu[c] - xr * mdxr[c]);
+                    const float dr = gr[c] * rr[c] * (du - mdu[c] - xr * mdxr[c]);
 #pragma unroll
                     for (int ci = 0; ci < CIN; ++ci) s[c * CIN + ci] = fmaf(dr, xv[ci], s[c * CIN + ci]);
                     s[C * CIN + c] += dr;
@@ -342,6 +363,11 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
 #pragma unroll
         for (int k = 0; k < K3; ++k) s[k] = 0.f;
         const float a1 = P_[b.prelu1];
+        float tw[C * C * KT], g1[C], b1p[C];
+#pragma unroll
+        for (int k = 0; k < C * C * KT; ++k) tw[k] = P_[b.tcn_w + k];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { g1[c] = P_[b.bn1_g + c]; b1p[c] = P_[b.bn1_b + c]; }
         for (int q = tid; q < cnt; q += NT) {
             const int t = q / vi, w = q - t * vi;
             float dh1[C];
@@ -357,13 +383,13 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
                 for (int c = 0; c < C; ++c) {
                     const float dv = DH2[(c * TP + t - dt + 2) * vi + w];
 #pragma unroll
-                    for (int ci = 0; ci < C; ++ci) dh1[ci] = fmaf(P_[b.tcn_w + (c * C + ci) * KT + dt], dv, dh1[ci]);
+                    for (int ci = 0; ci < C; ++ci) dh1[ci] = fmaf(tw[(c * C + ci) * KT + dt], dv, dh1[ci]);
                 }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const int i = (c * T + t) * vi + w;
                 const float x1 = (w_g[i] - m1[c]) * r1[c];
-                const float b1 = fmaf(x1, P_[b.bn1_g + c], P_[b.bn1_b + c]);
+                const float b1 = fmaf(x1, g1[c], b1p[c]);
                 float db = dh1[c];
                 if (!(b1 > 0.f)) {
                     db = a1 * dh1[c];
@@ -396,6 +422,13 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
 #pragma unroll
         for (int k = 0; k < K4; ++k) s[k] = 0.f;
         const bool want_dx = dxs != nullptr || dxg != nullptr;
+        float g1[C], gw[C * CIN];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            g1[c] = P_[b.bn1_g + c];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) gw[c * CIN + ci] = P_[b.gcn_w + c * CIN + ci];
+        }
         for (int q = tid; q < cnt; q += NT) {
             const int t = q / vi, w = q - t * vi;
             float axv[CIN], dax[CIN];
@@ -409,11 +442,11 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
             for (int c = 0; c < C; ++c) {
                 const int i = (c * T + t) * vi + w;
                 const float x1 = (w_g[i] - m1[c]) * r1[c];
-                const float dg = P_[b.bn1_g + c] * r1[c] * (DB1[i] - mdb[c] - x1 * mdbx[c]);
+                const float dg = g1[c] * r1[c] * (DB1[i] - mdb[c] - x1 * mdbx[c]);
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) {
                     s[c * CIN + ci] = fmaf(dg, axv[ci], s[c * CIN + ci]);
-                    dax[ci] = fmaf(P_[b.gcn_w + c * CIN + ci], dg, dax[ci]);
+                    dax[ci] = fmaf(gw[c * CIN + ci], dg, dax[ci]);
                 }
                 s[C * CIN + c] = fmaf(dg, csum, s[C * CIN + c]);
             }
@@ -477,7 +510,9 @@ __device__ void stgcn_block_bwd(const BwdArgs &a, const BlockLayout &b, int n, i
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, const float *params) {
+    // (unlike the forward kernel, params is NOT __restrict__ here: scalar-loading the weights into SGPRs pushed
+    // this kernel's SGPR spills up and measured 81 vs 69 us)
     constexpr int C = Cfg::C, T = Cfg::T, P = Cfg::P, NT = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int V = a.V, tid = threadIdx.x;
@@ -496,7 +531,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
     float *red = dcur + dcur_floats;                  // [WAVES*kRedMax]
     float *tot = red + WAVES * kRedMax;               // [kRedMax]
     float *saved = tot + kRedMax;                     // lean: [ax|cs|g|h2] of the scene, staged by LDS-DMA
-    const float *Pm = a.params;
+    const float *Pm = params;
 
     for (int e = tid; e < n_small; e += NT) gsm[e] = 0.f;
 
@@ -631,10 +666,10 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a) 
             float *dxs = j > 0 ? dcur : nullptr;
             float *dxg = j == 0 ? dxn : nullptr;
             if (L.blk[j].cin == Cfg::CIN0)
-                stgcn_block_bwd<Cfg::CIN0, WAVES>(a, L.blk[j], n, vi, dcur, H1, DH2, DB1, red, tot, gsm, wsn, xin,
+                stgcn_block_bwd<Cfg::CIN0, WAVES>(a, params, L.blk[j], n, vi, dcur, H1, DH2, DB1, red, tot, gsm, wsn, xin,
                                                   dxs, dxg, lean ? saved : nullptr);
             else
-                stgcn_block_bwd<Cfg::C, WAVES>(a, L.blk[j], n, vi, dcur, H1, DH2, DB1, red, tot, gsm, wsn, xin, dxs,
+                stgcn_block_bwd<Cfg::C, WAVES>(a, params, L.blk[j], n, vi, dcur, H1, DH2, DB1, red, tot, gsm, wsn, xin, dxs,
                                                dxg, lean ? saved : nullptr);
         }
     }
@@ -1078,7 +1113,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&model_bwd_kernel<W>),            \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
         if (e_ != hipSuccess) return hip_fail(e_, "stg_model_bwd: hipFuncSetAttribute");                     \
-        hipLaunchKernelGGL(model_bwd_kernel<W>, dim3(grid), dim3(W * 64), lds, st, a);                       \
+        hipLaunchKernelGGL(model_bwd_kernel<W>, dim3(grid), dim3(W * 64), lds, st, a, params);                       \
     } while (0)
     switch (waves) {
         case 1: STG_LAUNCH_BWD(1); break;

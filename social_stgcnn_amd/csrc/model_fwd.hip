@@ -60,13 +60,13 @@ __device__ __forceinline__ void block_sum(float (&v)[K], float *red) {
 //   layout), and, when `to_txp`, also scattered into the zero-bordered TXP plane `plane`.
 // ------------------------------------------------------------------------------------------
 template <int CIN, int WAVES>
-__device__ void stgcn_block_fwd(const FwdArgs &a, const BlockLayout &b, int n, int vi, const float *X, float *G,
+__device__ void stgcn_block_fwd(const FwdArgs &a, const float *__restrict__ P_, const float *__restrict__ B_,
+                                const BlockLayout &b, int n, int vi, const float *X, float *G,
                                 float *H, float *cs, float *red, float *wsn, float *statn, bool to_txp,
                                 float *plane, float *yblock, bool save_s) {
     constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, NT = WAVES * 64;
     const int tid = threadIdx.x, V = a.V;
     const int cnt = T * vi;
-    const float *P_ = a.params;
     const bool train = a.lay.bn_mode == 1;
     const float eps = a.lay.eps;
     const float *an = a.adj + n * a.a_sn;
@@ -143,8 +143,8 @@ __device__ void stgcn_block_fwd(const FwdArgs &a, const BlockLayout &b, int n, i
     } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            m1[c] = a.buffers[b.buf + c];
-            r1[c] = 1.0f / sqrtf(a.buffers[b.buf + C + c] + eps);
+            m1[c] = B_[b.buf + c];
+            r1[c] = 1.0f / sqrtf(B_[b.buf + C + c] + eps);
         }
         __syncthreads();
     }
@@ -255,11 +255,11 @@ __device__ void stgcn_block_fwd(const FwdArgs &a, const BlockLayout &b, int n, i
     } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            m2[c] = a.buffers[b.buf + 2 * C + c];
-            r2[c] = 1.0f / sqrtf(a.buffers[b.buf + 3 * C + c] + eps);
+            m2[c] = B_[b.buf + 2 * C + c];
+            r2[c] = 1.0f / sqrtf(B_[b.buf + 3 * C + c] + eps);
             if (b.residual == 2) {
-                mr[c] = a.buffers[b.buf + 4 * C + c];
-                rr[c] = 1.0f / sqrtf(a.buffers[b.buf + 5 * C + c] + eps);
+                mr[c] = B_[b.buf + 4 * C + c];
+                rr[c] = 1.0f / sqrtf(B_[b.buf + 5 * C + c] + eps);
             }
         }
         __syncthreads();
@@ -386,7 +386,11 @@ __device__ void txp_layer_fwd(const float *__restrict__ W, const float *__restri
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a) {
+__global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, const float *__restrict__ params,
+                                                               const float *__restrict__ buffers) {
+    // params / buffers are separate __restrict__ kernel arguments on purpose: only then can the compiler prove
+    // that the kernel's own stores never clobber them and fetch the (wave-uniform) weights with scalar loads
+    // into SGPRs instead of per-lane vector loads + s_waitcnt (340 vector loads per scene otherwise)
     constexpr int C = Cfg::C, T = Cfg::T, P = Cfg::P, NT = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int V = a.V, tid = threadIdx.x;
@@ -432,10 +436,10 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a) 
             const bool last = j == L.n_blocks - 1;
             float *yb = (last && L.n_txp == 0) ? yn : nullptr;
             if (L.blk[j].cin == Cfg::CIN0)
-                stgcn_block_fwd<Cfg::CIN0, WAVES>(a, L.blk[j], n, vi, X, G, H, cs, red, wsn, statn,
+                stgcn_block_fwd<Cfg::CIN0, WAVES>(a, params, buffers, L.blk[j], n, vi, X, G, H, cs, red, wsn, statn,
                                                   last && L.n_txp > 0, bufA, yb, !last);
             else
-                stgcn_block_fwd<Cfg::C, WAVES>(a, L.blk[j], n, vi, X, G, H, cs, red, wsn, statn,
+                stgcn_block_fwd<Cfg::C, WAVES>(a, params, buffers, L.blk[j], n, vi, X, G, H, cs, red, wsn, statn,
                                                last && L.n_txp > 0, bufA, yb, !last);
             float *tmp = X; X = H; H = tmp;      // block output becomes the next block's input
         }
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a) 
         float *bufB = reg;
         for (int e = tid; e < P * SC; e += NT) bufB[e] = 0.f;
         __syncthreads();
-        const float *Pm = a.params;
+        const float *__restrict__ Pm = params;
         float *in = bufA, *out = bufB;
         // a_l leaves as a whole zero-bordered plane, transposed to position-major [(C+2)*SW][P] with
         // coalesced stores: the layout the weight-gradient GEMM (K = positions, 16 lanes = 16 channels/taps)
@@ -545,7 +549,7 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&model_fwd_kernel<W>),            \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
         if (e_ != hipSuccess) return hip_fail(e_, "stg_model_fwd: hipFuncSetAttribute");                     \
-        hipLaunchKernelGGL(model_fwd_kernel<W>, grid, dim3(W * 64), lds, st, a);                             \
+        hipLaunchKernelGGL(model_fwd_kernel<W>, grid, dim3(W * 64), lds, st, a, params, buffers);                             \
     } while (0)
     switch (waves) {
         case 1: STG_LAUNCH_FWD(1); break;
