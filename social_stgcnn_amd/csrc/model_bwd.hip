@@ -608,7 +608,6 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
                 } else {
                     const float *zl = wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V;
                     float *dzo = a.dzg + ((int64_t)n * L.L + l) * dz_slot(V);
-                    const int dzs_ld = dz_stride(vi);
                     const float alpha = Pm[L.prelus + l];
                     float s[1] = {0.f};
                     constexpr int U = 4;                       // z loads in flight per lane
@@ -631,7 +630,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
                                     s[0] = fmaf(d, z, s[0]);
                                 }
                                 dzb[ch * SC + (h + 1) * SW + (w + 1)] = dz;
-                                dzo[ch * dzs_ld + p] = dz;
+                                dzo[p * P + ch] = dz;            // position-major hand-off [pos][12]
                             }
                         }
                     }
@@ -696,17 +695,17 @@ __device__ __forceinline__ void wave_dma_copy(const float *__restrict__ src, flo
 }
 
 // stage scene n of `layer` into one wave-private LDS image: a_l (zero-bordered, position-major
-// [(C+2)*SW][P]) and dz_l ([P][ld]); LDS-DMA where the source is linear (caller waits vmcnt(0))
+// [(C+2)*SW][P]) and dz_l (position-major [pos][P]); LDS-DMA where the source is linear (caller waits vmcnt(0))
 template <int CINL>
 __device__ __forceinline__ void wgrad_stage(const WgradArgs &a, int layer, int n, int vi, float *plane, float *dzs) {
     constexpr int C = Cfg::C, P = Cfg::P;
     const ModelLayout &L = a.lay;
     const int V = a.V, lane = threadIdx.x & 63;
-    const int SW = txp_sw(vi), npos = C * vi, ld = dz_stride(vi);
+    const int SW = txp_sw(vi), npos = C * vi;
     const float *wsn = a.ws + n * a.ws_stride;
     wave_dma_copy(wsn + ws_plane_off(L, V, layer), plane, ((C + 2) * SW * P + 3) >> 2);
     if (layer == L.L) {
-        // the output conv's dz is dy itself: (C*P) rows of V floats, vi valid -> [P][ld]
+        // the output conv's dz is dy itself: (C*P) rows of V floats, vi valid -> position-major [pos][P]
         const float *dyn = a.dy + (int64_t)n * (C * P) * V;
         constexpr int U = 8;
         for (int e0 = lane; e0 < P * npos; e0 += 64 * U) {
@@ -723,12 +722,12 @@ __device__ __forceinline__ void wgrad_stage(const WgradArgs &a, int layer, int n
                 const int e = e0 + 64 * u;
                 if (e < P * npos) {
                     const int co = e / npos;
-                    dzs[co * ld + (e - co * npos)] = dv[u];
+                    dzs[(e - co * npos) * P + co] = dv[u];
                 }
             }
         }
     } else {
-        wave_dma_copy(a.dzg + ((int64_t)n * L.L + layer) * dz_slot(V), dzs, (P * ld + 3) >> 2);
+        wave_dma_copy(a.dzg + ((int64_t)n * L.L + layer) * dz_slot(V), dzs, (P * npos) >> 2);
     }
 }
 
@@ -769,7 +768,7 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // image of scene n complete
         __builtin_amdgcn_wave_barrier();
         const float *plane = cur, *dzs = cur + pslot;
-        const int SW = txp_sw(vi), npos = C * vi, ld = dz_stride(vi);
+        const int SW = txp_sw(vi), npos = C * vi;
         int boff[NTILE];
 #pragma unroll
         for (int tl = 0; tl < NTILE; ++tl) {
@@ -781,13 +780,13 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
         const int nfull = vi >= 4 ? ((a.debug_skip & 128) ? 0 : (npos >> 2)) : 0;   // steps without a K tail
         int w = kq;                                  // vi >= 4 on the fast path: h = 0
         int pos_off = (SW + 1 + kq) * P;             // ((h+1)*SW + (w+1)) * P
-        int a_idx = co_a * ld + kq;
+        int a_idx = kq * P + co_a;                   // dz is position-major [pos][P]
         auto advance = [&]() {                       // p += 4 (vi >= 4: at most one row wrap)
             w += 4;
             const bool wrap = w >= vi;
             w -= wrap ? vi : 0;
             pos_off += wrap ? 6 * P : 4 * P;         // a wrap skips the two border columns (SW = vi + 2)
-            a_idx += 4;
+            a_idx += 4 * P;
         };
         int s = 0;
         for (; s + 2 <= nfull; s += 2) {
@@ -812,7 +811,7 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
             const bool ok = p < npos;
             const int pc = ok ? p : 0;
             const int hh = pc / vi, ww = pc - hh * vi;
-            const float av = ok ? dzs[co_a * ld + pc] : 0.f;
+            const float av = ok ? dzs[pc * P + co_a] : 0.f;
             const int offb = ((hh + 1) * SW + (ww + 1)) * P;
 #pragma unroll
             for (int tl = 0; tl < NTILE; ++tl) {

@@ -57,14 +57,8 @@ __host__ __device__ inline int txp_sc(int vi) {
 // [(C+2)*(vi+2) padded positions][P channels] (what the weight-gradient GEMM reads conflict-free); the
 // slot is sized by the channel-major LDS form P*txp_sc(V) >= P*(C+2)*(V+2).
 __host__ __device__ inline int plane_slot(int V) { return Cfg::P * txp_sc(V); }
-// row stride (floats) of a dz_l hand-off array [P][stride]: >= C*vi and == 2 (mod 4), so that the 12
-// channel rows x 2 K-lanes of a 16x16x4 A-operand read fall into distinct LDS banks
-__host__ __device__ inline int dz_stride(int vi) {
-    const int npos = Cfg::C * vi;
-    return npos + ((2 - npos) & 3);
-}
-// floats of one dz_l hand-off slot (padded batch V), multiple of 4
-__host__ __device__ inline int dz_slot(int V) { return (Cfg::P * dz_stride(V) + 3) & ~3; }
+// floats of one dz_l hand-off slot: position-major [C*V positions][P channels] (padded batch V)
+__host__ __device__ inline int dz_slot(int V) { return Cfg::P * Cfg::C * V; }
 
 // offset (floats, from the scene's workspace base, 16-byte aligned) of saved plane a_l
 __host__ __device__ inline int64_t ws_plane_off(const ModelLayout &l, int V, int idx) {

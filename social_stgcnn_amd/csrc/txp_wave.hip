@@ -321,7 +321,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
         for (int e = lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;
         return;
     }
-    const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi, ld = dz_stride(vi);
+    const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi;
     const float *Pm = a.params;
     const float *wsn = a.ws + n * a.ws_stride;
     const float *dyn = a.dy + (int64_t)n * (C * P) * V;
@@ -352,7 +352,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
             }
         } else {
             // dz_l = d(a_{l+1}) * prelu'(z_l); z is position-major [pos][12]; dz also leaves for the
-            // weight-gradient GEMM as [P][ld]
+            // weight-gradient GEMM, position-major as well (one 16-byte store per lane)
             const float *zl = wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V;
             float *dzo = a.dzg + ((int64_t)n * L.L + l) * dz_slot(V);
             const float alpha = Pm[L.prelus + l];
@@ -375,6 +375,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
                         const int p = vv / 3, q = vv - p * 3;       // position, channel quad
                         const unsigned hw = ptab[p];
                         const int h = (int)(hw >> 16), w = (int)(hw & 0xffffu);
+                        f32x4 dzv;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int ch = 4 * q + r;
@@ -385,8 +386,9 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
                                 slope_acc = fmaf(d, z, slope_acc);
                             }
                             dzb[ch * SC + (h + 1) * SW + (w + 1)] = dz;
-                            dzo[ch * ld + p] = dz;
+                            dzv[r] = dz;
                         }
+                        reinterpret_cast<f32x4 *>(dzo)[vv] = dzv;
                     }
                 }
             }
