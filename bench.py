@@ -109,6 +109,22 @@ def cpu_baseline(obs_rel, target, budget_s=15.0):
                       "ops, 1 thread" % (done, obs_rel.shape[1], dt)}
 
 
+def pmc_traffic(v, n):
+    """HBM bytes per stg_model_bwd launch from the committed rocprofv3 PMC passes (tools/gpu_traffic.sh:
+    FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950).  Counters cannot be collected inside this process, so the figure is the profiled one and only
+    reported for the workload it was profiled on (V=32, 2048 scene-windows); otherwise null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if (v, n) != (32, 2048) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    ks = ("txp_bwd_wave_kernel", "model_bwd_kernel", "txp_wgrad_kernel", "reduce_slabs_kernel")
+    if not all(k in t and "hbm_bytes_per_launch" in t[k] for k in ks):
+        return None
+    return sum(t[k]["hbm_bytes_per_launch"] for k in ks)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,7 +222,9 @@ def main():
                        + ("RCCL all-reduce + " if world > 1 else "") + "SGD update",
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": pmc_traffic(v, n),
+                         "traffic_note": "HBM bytes per stg_model_bwd launch, profiles/r01_pmc_traffic.json "
+                                         "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)",
                          "kernel": "stg_model_bwd = txp_bwd_wave_kernel + model_bwd_kernel + txp_wgrad_kernel + "
                                    "reduce_slabs_kernel (the backward of one batch)", "launch_ms": bwd_ms,
                          "algorithmic_flop_per_launch": bwd_flops,
