@@ -33,7 +33,7 @@ extern "C" {
 #define STG_EUNSUPPORTED (-2) /* configuration outside what the kernels are built for      */
 #define STG_ELDS (-3)        /* scene too large for the 160 KiB LDS of one CU             */
 
-#define STG_ABI_VERSION 3
+#define STG_ABI_VERSION 4
 #define STG_MAX_BLOCKS 4     /* st_gcn blocks in one fused model                          */
 
 int stg_abi_version(void);
@@ -163,6 +163,29 @@ int stg_nll_bwd(const float *grad, const float *gloss, int N, int P, int V, floa
 
 /* N3  optim.SGD(lr) step without momentum / weight decay (train.py:197): p -= lr * g.          */
 int stg_sgd_step(float *params, const float *grads, int64_t count, float lr, void *stream);
+
+/* N3  torch.nn.utils.clip_grad_norm_ (train.py:71-73) + optim.SGD step (train.py:197) + the StepLR-scheduled
+ *     learning rate (train.py:200) over the flat parameter / gradient buffers in one launch:
+ *       total = ||grads||_2;  if max_norm > 0: grads *= min(1, max_norm / (total + 1e-6)) (in place);
+ *       params -= lr * grads.   lr is read from device memory when lr_dev != NULL (so that a captured hipGraph
+ *     follows the schedule), else the host value `lr`.  grad_norm (1 float, may be NULL) receives `total`.
+ *     count <= 2^22 (single-workgroup kernel; the model has 7,563 parameters).                              */
+int stg_optim_step(float *params, float *grads, int64_t count, const float *lr_dev, float lr, float max_norm,
+                   float *grad_norm, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * N2  evaluation tail of test.test (test.py:59-123) + metrics.ade/fde/nodes_rel_to_nodes_abs
+ *     (metrics.py:21-75): per pedestrian the best-of-K average / final displacement error of K trajectories
+ *     sampled from the predicted bivariate Gaussians.  pred as in stg_nll_fwd; target_rel (N,P,V,2) ground-truth
+ *     displacements; obs_last (N,V,2) last observed absolute position (may be NULL: the errors are translation
+ *     invariant up to fp32 rounding); noise: K*N*P*V*2 standard normals laid out (K,N,P,V,2), or NULL to draw
+ *     them in the kernel (Philox4x32-10 keyed by `seed`, counter = (scene*V + ped, k*P + t)).
+ *     sample = mean + chol(cov) * eps, trajectory = cumsum_t(sample) + obs_last; ade/fde (N,V) receive
+ *     min_k mean_t |traj - truth| and min_k |traj_P - truth_P| (0 for padded pedestrians).
+ */
+int stg_bestofk_eval(const float *pred, int64_t p_sn, int64_t p_sf, int64_t p_sp, int64_t p_sv,
+                     const float *target_rel, const float *obs_last, const int32_t *num_peds, const float *noise,
+                     uint64_t seed, int N, int P, int V, int K, float *ade, float *fde, void *stream);
 
 /* Self-test helper: C(16x16) = A(16xK) * B(Kx16) through v_mfma_f32_16x16x4_f32 with the operand
  * maps the TXP-CNN kernels rely on (K multiple of 4).                                           */

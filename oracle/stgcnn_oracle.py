@@ -306,3 +306,31 @@ def best_of_k_errors(v_pred, obs_abs_last, target_rel, k_steps, generator=None):
             ade[n].append(float(err[:, n].mean()))
             fde[n].append(float(err[-1, n]))
     return [min(a) for a in ade], [min(f) for f in fde]
+
+
+def best_of_k_errors_noise(v_pred, obs_abs_last, target_rel, eps):
+    """`best_of_k_errors` with the standard-normal draws handed in: eps (K,P,V,2) torch fp32.
+    MultivariateNormal.sample() is `loc + scale_tril @ standard_normal(shape)` with scale_tril =
+    cholesky(cov) (test.py:59-71 builds cov, :89 samples), so with eps[k] = the k-th draw of the CPU
+    generator this returns exactly what `best_of_k_errors` returns (pinned in tests/test_oracle.py)."""
+    sx = torch.exp(v_pred[:, :, 2])
+    sy = torch.exp(v_pred[:, :, 3])
+    corr = torch.tanh(v_pred[:, :, 4])
+    cov = torch.zeros(v_pred.shape[0], v_pred.shape[1], 2, 2)
+    cov[:, :, 0, 0] = sx * sx
+    cov[:, :, 0, 1] = corr * sx * sy
+    cov[:, :, 1, 0] = corr * sx * sy
+    cov[:, :, 1, 1] = sy * sy
+    tril = torch.linalg.cholesky(cov)
+    tgt_abs = rel_to_abs(np.asarray(target_rel, dtype=np.float64), np.asarray(obs_abs_last))
+    n_ped = v_pred.shape[1]
+    ade = [[] for _ in range(n_ped)]
+    fde = [[] for _ in range(n_ped)]
+    for k in range(eps.shape[0]):
+        s = (v_pred[:, :, 0:2] + torch.matmul(tril, eps[k].unsqueeze(-1)).squeeze(-1)).numpy()
+        s_abs = rel_to_abs(s.astype(np.float32), np.asarray(obs_abs_last, dtype=np.float32))
+        err = np.sqrt(((s_abs.astype(np.float64) - tgt_abs) ** 2).sum(axis=2))
+        for n in range(n_ped):
+            ade[n].append(float(err[:, n].mean()))
+            fde[n].append(float(err[-1, n]))
+    return [min(a) for a in ade], [min(f) for f in fde]

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libstgcnn_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_f = ctypes.c_void_p          # device pointers travel as void*
 c_i = ctypes.c_int
@@ -51,6 +51,9 @@ _SIGNATURES = {
     "stg_nll_fwd": (c_i, [c_f, c_l, c_l, c_l, c_l, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f]),
     "stg_nll_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
     "stg_sgd_step": (c_i, [c_f, c_f, c_l, ctypes.c_float, c_f]),
+    "stg_optim_step": (c_i, [c_f, c_f, c_l, c_f, ctypes.c_float, ctypes.c_float, c_f, c_f]),
+    "stg_bestofk_eval": (c_i, [c_f, c_l, c_l, c_l, c_l, c_f, c_f, c_f, c_f, ctypes.c_uint64, c_i, c_i, c_i, c_i,
+                               c_f, c_f, c_f]),
     "stg_selftest_mfma": (c_i, [c_f, c_f, c_i, c_f, c_f]),
 }
 EXPORTS = tuple(_SIGNATURES)

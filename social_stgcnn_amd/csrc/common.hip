@@ -26,6 +26,41 @@ __global__ void sgd_kernel(float *__restrict__ p, const float *__restrict__ g, i
     if (i < n) p[i] = p[i] - lr * g[i];
 }
 
+// clip_grad_norm_ (train.py:71-73) + SGD (train.py:197) over the flat buffers in ONE single-workgroup launch:
+// total = ||g||_2, coef = min(1, max_norm / (total + 1e-6)), g *= coef (in place, as torch does), p -= lr g.
+// lr comes from device memory when lr_dev != NULL, so a captured hipGraph follows the StepLR schedule.
+__global__ __launch_bounds__(1024) void optim_step_kernel(float *__restrict__ p, float *__restrict__ g, int64_t n,
+                                                          const float *__restrict__ lr_dev, float lr_host,
+                                                          float max_norm, float *__restrict__ norm_out) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    const float lr = lr_dev ? lr_dev[0] : lr_host;
+    float coef = 1.f;
+    if (max_norm > 0.f || norm_out) {
+        float acc = 0.f;
+        for (int64_t i = tid; i < n; i += blockDim.x) acc = fmaf(g[i], g[i], acc);
+        acc = wave_sum(acc);
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+        __syncthreads();
+        float tot = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+        const float nrm = sqrtf(tot);
+        if (norm_out && tid == 0) norm_out[0] = nrm;
+        if (max_norm > 0.f) {
+            coef = max_norm / (nrm + 1e-6f);
+            coef = coef > 1.f ? 1.f : coef;
+        }
+    }
+    for (int64_t i = tid; i < n; i += blockDim.x) {
+        float gi = g[i];
+        if (max_norm > 0.f) {
+            gi *= coef;
+            g[i] = gi;
+        }
+        p[i] = p[i] - lr * gi;
+    }
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // One wave: C(16x16) = A(16xK) B(Kx16).  A operand: lane l holds A[l&15][4s + (l>>4)];
@@ -60,6 +95,18 @@ int stg_sgd_step(float *params, const float *grads, int64_t count, float lr, voi
     hipLaunchKernelGGL(stg::sgd_kernel, dim3((unsigned)blocks), dim3(threads), 0, stg::as_stream(stream),
                        params, grads, count, lr);
     STG_LAUNCH_CHECK("stg_sgd_step");
+    return STG_OK;
+}
+
+int stg_optim_step(float *params, float *grads, int64_t count, const float *lr_dev, float lr, float max_norm,
+                   float *grad_norm, void *stream) {
+    STG_REQUIRE(params && grads && count >= 0, STG_EINVAL, "stg_optim_step: null pointer or negative count");
+    STG_REQUIRE(count <= (1ll << 22), STG_EUNSUPPORTED,
+                "stg_optim_step: %lld parameters exceed the single-workgroup step (use stg_sgd_step)", (long long)count);
+    if (count == 0) return STG_OK;
+    hipLaunchKernelGGL(stg::optim_step_kernel, dim3(1), dim3(1024), 0, stg::as_stream(stream), params, grads, count,
+                       lr_dev, lr, max_norm, grad_norm);
+    STG_LAUNCH_CHECK("stg_optim_step");
     return STG_OK;
 }
 

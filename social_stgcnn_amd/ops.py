@@ -361,3 +361,41 @@ def sgd_step(flat_params, flat_grads, lr):
     require_gpu(flat_params, flat_grads)
     check(lib().stg_sgd_step(ptr(flat_params), ptr(flat_grads), flat_params.numel(), float(lr), stream_ptr()),
           "stg_sgd_step")
+
+
+def optim_step(flat_params, flat_grads, lr, max_norm=None, lr_dev=None, grad_norm=None):
+    """clip_grad_norm_(max_norm) + SGD(lr) on the flat buffers in one launch (train.py:71-74,197).  `lr_dev`
+    (1-element device tensor) overrides `lr` -- the form a captured hipGraph needs to follow StepLR; `grad_norm`
+    (1-element device tensor) receives the unclipped gradient norm.  The gradients are scaled in place."""
+    require_gpu(flat_params, flat_grads)
+    check(lib().stg_optim_step(ptr(flat_params), ptr(flat_grads), flat_params.numel(), ptr(lr_dev), float(lr),
+                               float(max_norm) if max_norm is not None else 0.0, ptr(grad_norm), stream_ptr()),
+          "stg_optim_step")
+
+
+def best_of_k(y, target_rel, obs_last=None, num_peds=None, k=20, noise=None, seed=0):
+    """Evaluation tail of test.py:59-123 on the device: y (N,5,P,V) model output (any strides), target_rel
+    (N,P,V,2), obs_last (N,V,2) or None, noise (K,N,P,V,2) standard normals or None (in-kernel Philox stream keyed
+    by `seed`).  Returns per-pedestrian (min ADE, min FDE), each (N,V) with zeros in padded slots."""
+    require_gpu(y, target_rel)
+    n, f, p, v = y.shape
+    if f != 5 or tuple(target_rel.shape) != (n, p, v, 2):
+        raise ValueError("best_of_k: y (N,5,P,V) / target_rel (N,P,V,2) expected")
+    y = y.to(torch.float32)
+    target_rel = target_rel.to(torch.float32).contiguous()
+    if obs_last is not None:
+        if tuple(obs_last.shape) != (n, v, 2):
+            raise ValueError("best_of_k: obs_last (N,V,2) expected")
+        obs_last = obs_last.to(device=y.device, dtype=torch.float32).contiguous()
+    if noise is not None:
+        if tuple(noise.shape) != (k, n, p, v, 2):
+            raise ValueError("best_of_k: noise (K,N,P,V,2) expected")
+        noise = noise.to(device=y.device, dtype=torch.float32).contiguous()
+    peds = peds_arg(num_peds, n, y.device)
+    ade = torch.empty((n, v), device=y.device, dtype=torch.float32)
+    fde = torch.empty((n, v), device=y.device, dtype=torch.float32)
+    sn, sf, sp, sv = y.stride()
+    check(lib().stg_bestofk_eval(ptr(y), sn, sf, sp, sv, ptr(target_rel), ptr(obs_last), ptr(peds), ptr(noise),
+                                 int(seed) & 0xFFFFFFFFFFFFFFFF, n, p, v, int(k), ptr(ade), ptr(fde), stream_ptr()),
+          "stg_bestofk_eval")
+    return ade, fde

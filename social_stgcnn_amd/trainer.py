@@ -15,6 +15,7 @@ running statistics are folded across ranks in rank order so that R ranks x B sce
 processing the concatenated R*B scenes.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -94,15 +95,41 @@ def group_bounds(n_scenes, batch_size):
 class Trainer:
     """SGD trainer over the fused HIP path."""
 
-    def __init__(self, model, lr=0.01, clip_grad=None, group=None):
+    def __init__(self, model, lr=0.01, clip_grad=None, group=None, lr_sh_rate=None, lr_gamma=0.2):
+        """lr / clip_grad as train.py:152-156,197; lr_sh_rate = StepLR step size in epochs (train.py:200,
+        `--lr_sh_rate`, used when `--use_lrschd`), lr_gamma its decay (0.2 in the reference)."""
         self.model = model
-        self.lr = lr
+        self.base_lr = float(lr)
+        self.lr = float(lr)
         self.clip_grad = clip_grad
         self.group = group
+        self.lr_sh_rate = lr_sh_rate
+        self.lr_gamma = lr_gamma
+        self.epoch = 0
+        self._lr_dev = None                  # device copy of lr read by the update kernel (graph-safe)
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
     def _bn_buffers(self):
         return self.model._tensors()[1]
+
+    def _lr_tensor(self, device):
+        if self._lr_dev is None or self._lr_dev.device != device:
+            self._lr_dev = torch.full((1,), self.lr, device=device, dtype=torch.float32)
+        return self._lr_dev
+
+    def scheduler_step(self):
+        """StepLR.step() (train.py:200,222-223): once per epoch; lr = base_lr * gamma ** (epoch // lr_sh_rate).
+        The device copy is refreshed in place, so captured steps follow the schedule."""
+        self.epoch += 1
+        if self.lr_sh_rate:
+            self.lr = self.base_lr * self.lr_gamma ** (self.epoch // int(self.lr_sh_rate))
+            if self._lr_dev is not None:
+                self._lr_dev.fill_(self.lr)
+        return self.lr
+
+    def _update(self, flat_p, flat_g):
+        """clip_grad_norm_ + SGD update over the flat buffers: one launch (train.py:71-74)."""
+        ops.optim_step(flat_p, flat_g, self.lr, self.clip_grad, self._lr_tensor(flat_p.device))
 
     def forward_backward(self, x, adj, target, num_peds=None, weights=None):
         """One fused forward + loss + backward.  x (N,2,T,V) (any strides), adj (N,T,V,V) or (T,V,V),
@@ -134,10 +161,7 @@ class Trainer:
             mom = model.st_gcns[0].tcn[0].momentum
             flat_b = model._pb.flat
             flat_b.copy_(fold_bn_across_ranks(before, flat_b.clone(), n_local, mom, self.group))
-        if self.clip_grad is not None:
-            torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], self.clip_grad)
-            flat_g = self._flat_grad()
-        ops.sgd_step(flat_p, flat_g, self.lr)
+        self._update(flat_p, flat_g)
         return total, losses, y
 
     # ---- hipGraph capture of the step (launch-bound at these sizes: ~15 kernels of 10-150 us) ----------
@@ -158,6 +182,7 @@ class Trainer:
         flat_p = model.flat_parameters()
         flat_b = model._pb.ensure(self._bn_buffers())
         nbt = model._tensors()[2]
+        self._lr_tensor(flat_p.device)       # allocate outside the capture
         saved = (flat_p.clone(), flat_b.clone(), [t.clone() for t in nbt])
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -198,7 +223,7 @@ class Trainer:
             pack[n_p:].mul_(later)
         with torch.cuda.graph(g_b, pool=g_a.pool()):
             torch.add(pack[n_p:], before, alpha=total, out=flat_b)
-            ops.sgd_step(flat_p, pack[:n_p], self.lr)
+            self._update(flat_p, pack[:n_p])
         self._graph = (g_a, g_b)
 
         def replay():
@@ -294,3 +319,77 @@ def evaluate_ade_fde(model, batches, k_steps=20):
             ades += [min(a) for a in a_ls]
             fdes += [min(f) for f in f_ls]
     return float(np.mean(ades)), float(np.mean(fdes)), ades, fdes
+
+
+@torch.no_grad()
+def evaluate_ade_fde_device(model, batches, k_steps=20, seed=0, noise_fn=None):
+    """test.test() (test.py:18-127) with the sampling and the best-of-k displacement errors on the device
+    (`ops.best_of_k`: one launch per batch instead of O(k V P) Python loops per scene).
+
+    batches: as for `evaluate_ade_fde`.  The draws come from the kernel's Philox stream keyed by `seed` + batch
+    index, or from `noise_fn(batch_index, (k, N, P, V, 2))` -> standard normals (parity tests feed the CPU
+    sampler's numbers).  Statistically, not bitwise, equal to the reference's CPU draws.
+    Returns (ade, fde, per_ped_ade, per_ped_fde)."""
+    model.eval()
+    ades, fdes = [], []
+    for b, (x, adj, peds, obs_last, tgt_rel) in enumerate(batches):
+        y, _ = model(x, adj, peds)
+        n, _, p, v = y.shape
+        dev = y.device
+        tgt_rel = torch.as_tensor(tgt_rel).to(dev)
+        obs_last = None if obs_last is None else torch.as_tensor(obs_last).to(dev)
+        noise = noise_fn(b, (k_steps, n, p, v, 2)) if noise_fn is not None else None
+        a, f = ops.best_of_k(y, tgt_rel, obs_last, peds, k_steps, noise, seed + b)
+        if peds is None:
+            mask = torch.ones((n, v), dtype=torch.bool, device=dev)
+        else:
+            counts = torch.as_tensor(peds).to(device=dev, dtype=torch.int64)
+            mask = torch.arange(v, device=dev)[None, :] < counts[:, None]
+        ades.append(a[mask])
+        fdes.append(f[mask])
+    ades = torch.cat(ades).cpu().numpy().astype(np.float64)
+    fdes = torch.cat(fdes).cpu().numpy().astype(np.float64)
+    return float(ades.mean()), float(fdes.mean()), ades.tolist(), fdes.tolist()
+
+
+# ------------------------------------------------------------------------------------------
+# checkpoint files of train.py:202-246 (what test.py:134-160 reads back)
+# ------------------------------------------------------------------------------------------
+class Checkpoint:
+    """`<dir>/val_best.pth` (state_dict, 40 keys), `args.pkl`, `metrics.pkl`, `constant_metrics.pkl` with the
+    bookkeeping of train.py:213-246: `record(epoch, train_loss, val_loss)` appends the losses, saves the model
+    when the validation loss improves and rewrites the two metric files."""
+
+    def __init__(self, directory, args=None):
+        import pickle
+        self.dir = directory
+        os.makedirs(directory, exist_ok=True)
+        self.metrics = {"train_loss": [], "val_loss": []}
+        self.constant_metrics = {"min_val_epoch": -1, "min_val_loss": 9999999999999999}
+        if args is not None:
+            with open(os.path.join(directory, "args.pkl"), "wb") as fp:
+                pickle.dump(args, fp)
+
+    def record(self, epoch, model, train_loss, val_loss):
+        import pickle
+        self.metrics["train_loss"].append(train_loss)
+        self.metrics["val_loss"].append(val_loss)
+        improved = val_loss < self.constant_metrics["min_val_loss"]
+        if improved:
+            self.constant_metrics["min_val_loss"] = val_loss
+            self.constant_metrics["min_val_epoch"] = epoch
+            state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+            torch.save(state, os.path.join(self.dir, "val_best.pth"))
+        with open(os.path.join(self.dir, "metrics.pkl"), "wb") as fp:
+            pickle.dump(self.metrics, fp)
+        with open(os.path.join(self.dir, "constant_metrics.pkl"), "wb") as fp:
+            pickle.dump(self.constant_metrics, fp)
+        return improved
+
+
+def load_checkpoint(model, path, map_location="cpu"):
+    """model.load_state_dict(torch.load(val_best.pth)) (test.py:158) with the loader that executes nothing from
+    the file."""
+    state = torch.load(path, map_location=map_location, weights_only=True)
+    model.load_state_dict(state)
+    return model

@@ -86,3 +86,47 @@ def test_data_parallel_pieces_gloo_world2():
         p.join(120)
         assert p.exitcode == 0
     assert sorted(out.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_checkpoint_files_follow_the_reference_layout(tmp_path):
+    """N4 (train.py:202-246): args.pkl / metrics.pkl / constant_metrics.pkl / val_best.pth; the saved state_dict has
+    the reference's 40 keys, loads with weights_only=True and round-trips into a fresh model."""
+    import argparse
+    import pickle
+    from oracle import stgcnn_oracle as o
+    from social_stgcnn_amd.model import social_stgcnn
+    from social_stgcnn_amd.trainer import Checkpoint, load_checkpoint
+    torch.manual_seed(0)
+    m = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3, pred_seq_len=12)
+    d = str(tmp_path / "checkpoint" / "tag")
+    ck = Checkpoint(d, argparse.Namespace(n_stgcnn=1, n_txpcnn=5, lr=0.01, tag="tag"))
+    assert ck.record(0, m, 1.5, 2.0) is True
+    with torch.no_grad():
+        m.tpcnn_ouput.bias.add_(1.0)
+    assert ck.record(1, m, 1.4, 2.5) is False                      # worse validation loss: no save
+    assert ck.record(2, m, 1.3, 1.0) is True
+    with open(d + "/metrics.pkl", "rb") as fp:
+        assert pickle.load(fp) == {"train_loss": [1.5, 1.4, 1.3], "val_loss": [2.0, 2.5, 1.0]}
+    with open(d + "/constant_metrics.pkl", "rb") as fp:
+        assert pickle.load(fp) == {"min_val_epoch": 2, "min_val_loss": 1.0}
+    with open(d + "/args.pkl", "rb") as fp:
+        assert pickle.load(fp).n_txpcnn == 5
+    sd = torch.load(d + "/val_best.pth", weights_only=True)
+    assert list(sd.keys()) == list(o.state_dict_keys())
+    m2 = load_checkpoint(social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3,
+                                       pred_seq_len=12), d + "/val_best.pth")
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+
+
+def test_step_lr_schedule_matches_torch():
+    from social_stgcnn_amd.model import social_stgcnn
+    from social_stgcnn_amd.trainer import Trainer
+    m = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3, pred_seq_len=12)
+    tr = Trainer(m, lr=0.01, lr_sh_rate=3)
+    opt = torch.optim.SGD(m.parameters(), lr=0.01)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=3, gamma=0.2)
+    for _ in range(10):
+        opt.step()
+        sched.step()
+        assert abs(tr.scheduler_step() - opt.param_groups[0]["lr"]) < 1e-12

@@ -169,3 +169,21 @@ def test_eval_ade_fde_matches_reference_test():
     np.testing.assert_allclose(fdes, g["per_ped_fde"], rtol=0, atol=2e-5)
     assert abs(np.mean(ades) - float(g["ade"])) < 1e-5
     assert abs(np.mean(fdes) - float(g["fde"])) < 1e-5
+
+
+def test_best_of_k_noise_variant_is_the_sampler_variant():
+    """oracle.best_of_k_errors_noise (the checker of the device evaluation op) == oracle.best_of_k_errors (pinned
+    by the reference's test() golden) when eps is the CPU generator's own stream."""
+    from oracle import stgcnn_oracle as o
+    g = np.random.default_rng(0)
+    p, v, k = 12, 5, 20
+    torch.manual_seed(3)
+    vp = torch.randn(p, v, 5) * 0.5
+    obs = (g.normal(size=(v, 2)) * 5).astype(np.float32)
+    tgt = (g.normal(size=(p, v, 2)) * 0.3).astype(np.float32)
+    torch.manual_seed(11)
+    a1, f1 = o.best_of_k_errors(vp, obs, tgt, k)
+    torch.manual_seed(11)
+    eps = torch.stack([torch.randn(p, v, 2) for _ in range(k)])
+    a2, f2 = o.best_of_k_errors_noise(vp, obs, tgt, eps)
+    assert a1 == a2 and f1 == f2
