@@ -56,6 +56,22 @@ def synth_scenes(n, v, seed):
     return obs_rel, target
 
 
+# pedestrians per scene-window of eth/train (2785 windows, mean 10.7, median 5, max 57), index = V:
+# measured with social_stgcnn_amd.data.load_windows on the dataset's text files -- the shape of real ragged batches
+ETH_TRAIN_PEDS_HIST = [0, 0, 559, 371, 319, 226, 163, 117, 84, 84, 46, 27, 24, 31, 16, 19, 17, 22, 32, 23, 31, 35, 40,
+                       36, 35, 37, 22, 16, 19, 28, 29, 24, 31, 29, 30, 16, 20, 20, 21, 22, 7, 5, 6, 9, 4, 7, 6, 2, 4, 3,
+                       1, 5, 2, 2, 0, 0, 0, 1]
+
+
+def ragged_counts(n, seed, order="shuffled"):
+    """n pedestrian counts drawn from the eth/train histogram (BASELINE configs[1]: 'ETH train, batch=512')."""
+    h = np.asarray(ETH_TRAIN_PEDS_HIST, dtype=np.float64)
+    c = np.random.default_rng(seed).choice(len(h), size=n, p=h / h.sum()).astype(np.int32)
+    if order == "sorted":
+        c = np.sort(c)[::-1].copy()
+    return c
+
+
 def flops_per_window(v, fwd=True, bwd=True):
     """SURVEY 8d algorithmic work per scene-window (matches torch FlopCounterMode on the reference)."""
     f = 62000 * v + 80 * v * v
@@ -79,7 +95,7 @@ def time_kernel(fn, iters=20, warm=3):
     return a.elapsed_time(b) / iters
 
 
-def cpu_baseline(obs_rel, target, budget_s=15.0):
+def cpu_baseline(obs_rel, target, budget_s=15.0, counts=None):
     """The oracle, driven like train.py:36-77 drives the reference: one scene per forward (N = 1),
     loss, backward -- single thread, bounded sample of the same workload."""
     from oracle import stgcnn_oracle as O
@@ -91,9 +107,10 @@ def cpu_baseline(obs_rel, target, budget_s=15.0):
     keys = [k for k, _ in m.named_parameters()]
     scenes = []
     for i in range(min(64, obs_rel.shape[0])):
-        nodes, lap = O.seq_to_graph_np(obs_rel[i])
+        c = obs_rel.shape[1] if counts is None else int(counts[i])
+        nodes, lap = O.seq_to_graph_np(obs_rel[i, :c])
         scenes.append((torch.from_numpy(nodes).unsqueeze(0).permute(0, 3, 1, 2), torch.from_numpy(lap),
-                       torch.from_numpy(target[i])))
+                       torch.from_numpy(np.ascontiguousarray(target[i, :, :c]))))
     done, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
         x, a, tgt = scenes[done % len(scenes)]
@@ -132,6 +149,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=2048, help="scene-windows per GPU")
     ap.add_argument("--peds", type=int, default=32, help="pedestrians per scene-window (V)")
+    ap.add_argument("--ragged", choices=("shuffled", "sorted"), default=None,
+                    help="ragged batch: pedestrians per scene drawn from the eth/train histogram (padded to the "
+                         "largest draw); 'sorted' orders the scenes by crowd size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -160,10 +180,19 @@ def main():
     from social_stgcnn_amd.trainer import Trainer, broadcast_module
 
     n, v = args.batch, args.peds
+    counts, peds_d = None, None
+    if args.ragged:
+        counts = ragged_counts(n, seed=1 + rank, order=args.ragged)
+        v = int(counts.max())
     obs_rel, target = synth_scenes(n, v, seed=1 + rank)
+    if counts is not None:
+        live = np.arange(v)[None, :] < counts[:, None]                  # (N,V)
+        obs_rel *= live[:, :, None, None]
+        target *= live[:, None, :, None]
+        peds_d = torch.from_numpy(counts).to(dev)
     rel_d = torch.from_numpy(obs_rel).to(dev)
     tgt_d = torch.from_numpy(target).to(dev)
-    nodes, adj = ops.adj_build(rel_d)                     # graph build stays on the device
+    nodes, adj = ops.adj_build(rel_d, peds_d)             # graph build stays on the device
     x = nodes.permute(0, 3, 1, 2)                         # (N,2,T,V) strided view like train.py:48
     weights = torch.full((n,), 1.0 / (n * world), device=dev)
 
@@ -175,9 +204,9 @@ def main():
 
     if args.no_graph:
         def step():
-            return trainer.step(x, adj, tgt_d, None, weights)
+            return trainer.step(x, adj, tgt_d, peds_d, weights)
     else:
-        step = trainer.capture(x, adj, tgt_d, None, weights)      # the whole step as one hipGraph
+        step = trainer.capture(x, adj, tgt_d, peds_d, weights)      # the whole step as one hipGraph
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -195,7 +224,7 @@ def main():
     # per-call device time of the forward / backward entry points: the same K steps once more, launched
     # eagerly with HIP-event brackets on the launch stream (a replayed hipGraph cannot be bracketed per node)
     for _ in range(args.steps):
-        trainer.step(x, adj, tgt_d, None, weights)
+        trainer.step(x, adj, tgt_d, peds_d, weights)
     torch.cuda.synchronize()
     timer, ops.TIMER = ops.TIMER, None
     if world > 1:
@@ -208,7 +237,18 @@ def main():
         value = world * n * args.steps / elapsed
         bwd_ms = timer.mean_ms("model_bwd")
         fwd_ms = timer.mean_ms("model_fwd")
-        bwd_flops = flops_per_window(v, fwd=False) * n
+        per_scene = [v] * n if counts is None else [int(c) for c in counts]
+        bwd_flops = sum(flops_per_window(c, fwd=False) for c in per_scene)
+        fwd_flops = sum(flops_per_window(c, bwd=False) for c in per_scene)
+        all_flops = sum(flops_per_window(c) for c in per_scene) / n
+        all_bytes = sum(bytes_per_window(c) for c in per_scene) / n
+        if counts is None:
+            workload = ("synthetic V=%d scene-windows, obs 8 / pred 12, batch %d per GPU, fp32 (BASELINE north-star: "
+                        "V<=32, batch=2048; SURVEY 8d generator)" % (v, n))
+        else:
+            workload = ("synthetic ragged scene-windows, pedestrians per window drawn from the eth/train histogram "
+                        "(mean %.1f, max %d, %s order), obs 8 / pred 12, batch %d per GPU, fp32 (BASELINE configs[1] "
+                        "shape)" % (float(counts.mean()), v, args.ragged, n))
         achieved = bwd_flops / (bwd_ms * 1e-3) / 1e12
         out = {
             "metric": "scene-windows/sec fwd+bwd (obs=8,pred=12)",
@@ -216,25 +256,24 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "launch": "eager" if args.no_graph else "hipGraph replay",
-            "config": {"workload": "synthetic V=%d scene-windows, obs 8 / pred 12, batch %d per GPU, fp32 "
-                                   "(BASELINE north-star: V<=32, batch=2048; SURVEY 8d generator)" % (v, n),
+            "config": {"workload": workload,
                        "global_batch": n * world, "step": "forward + bivariate NLL + backward + "
                        + ("RCCL all-reduce + " if world > 1 else "") + "SGD update",
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": pmc_traffic(v, n),
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": pmc_traffic(v, n) if counts is None else None,
                          "traffic_note": "HBM bytes per stg_model_bwd launch, profiles/r01_pmc_traffic.json "
                                          "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)",
                          "kernel": "stg_model_bwd = txp_bwd_wave_kernel + model_bwd_kernel + txp_wgrad_kernel + "
                                    "reduce_slabs_kernel (the backward of one batch)", "launch_ms": bwd_ms,
                          "algorithmic_flop_per_launch": bwd_flops,
                          "fwd_kernel": {"kernel": "stg_model_fwd = model_fwd_kernel + txp_fwd_wave_kernel", "launch_ms": fwd_ms,
-                                        "achieved": flops_per_window(v, bwd=False) * n / (fwd_ms * 1e-3) / 1e12}},
-            "end_to_end": {"algorithmic_tflops": flops_per_window(v) * value / 1e12,
-                           "algorithmic_gbs": bytes_per_window(v) * value / 1e9},
+                                        "achieved": fwd_flops / (fwd_ms * 1e-3) / 1e12}},
+            "end_to_end": {"algorithmic_tflops": all_flops * value / 1e12,
+                           "algorithmic_gbs": all_bytes * value / 1e9},
         }
         # stand-alone bandwidth kernels (north-star: achieved HBM GB/s vs the gfx950 peak)
-        adj_ms = time_kernel(lambda: ops.adj_build(rel_d))
+        adj_ms = time_kernel(lambda: ops.adj_build(rel_d, peds_d))
         agg_in = torch.randn(n, 5, T_OBS, v, device=dev)
         agg_ms = time_kernel(lambda: ops.spatial_agg(agg_in, adj))
         adj_bytes = n * (64 * v + 32 * v * v + 64 * v)
@@ -245,7 +284,7 @@ def main():
                                 "frac_hbm": agg_bytes / agg_ms / 1e6 / PEAK_HBM_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(obs_rel, target, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(obs_rel, target, args.cpu_seconds, counts)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

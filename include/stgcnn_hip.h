@@ -164,6 +164,15 @@ int stg_nll_bwd(const float *grad, const float *gloss, int N, int P, int V, floa
 /* N3  optim.SGD(lr) step without momentum / weight decay (train.py:197): p -= lr * g.          */
 int stg_sgd_step(float *params, const float *grads, int64_t count, float lr, void *stream);
 
+/* Ragged batches (the reference's DataLoader yields scenes of 2..57 pedestrians, utils.py:121-193): order[0..N) =
+ * scene indices sorted by clamp(num_peds[n], 0, V) descending, stable.  stg_model_fwd / stg_model_bwd run this
+ * themselves when num_peds is given (into their scratch buffers) and deal the sorted scenes to their persistent
+ * waves boustrophedon, so a padded ragged batch is load-balanced; exported for callers that schedule their own
+ * work the same way.  key_start (V+2 ints, may be NULL): key_start[k] = number of scenes with more than V-k
+ * pedestrians, so the scenes with at most x pedestrians are order[key_start[V-x] .. N).
+ * 2 <= N <= 65536, V <= 1023 (one workgroup, per-wave key histograms in LDS).                                                   */
+int stg_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, int32_t *key_start, void *stream);
+
 /* N3  torch.nn.utils.clip_grad_norm_ (train.py:71-73) + optim.SGD step (train.py:197) + the StepLR-scheduled
  *     learning rate (train.py:200) over the flat parameter / gradient buffers in one launch:
  *       total = ||grads||_2;  if max_norm > 0: grads *= min(1, max_norm / (total + 1e-6)) (in place);

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "stg_nll_fwd": (c_i, [c_f, c_l, c_l, c_l, c_l, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f]),
     "stg_nll_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
     "stg_sgd_step": (c_i, [c_f, c_f, c_l, ctypes.c_float, c_f]),
+    "stg_scene_order": (c_i, [c_f, c_i, c_i, c_f, c_f, c_f]),
     "stg_optim_step": (c_i, [c_f, c_f, c_l, c_f, ctypes.c_float, ctypes.c_float, c_f, c_f]),
     "stg_bestofk_eval": (c_i, [c_f, c_l, c_l, c_l, c_l, c_f, c_f, c_f, c_f, ctypes.c_uint64, c_i, c_i, c_i, c_i,
                                c_f, c_f, c_f]),

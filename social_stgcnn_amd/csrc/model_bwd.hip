@@ -36,6 +36,8 @@ struct BwdArgs {
     float *slab1;     // K1 slab rows: [gridDim.x][n_blk_params + n_txp]
     float *dzg;       // dz_l of the hidden TXP layers for K2: [N][L][P*C*V]
     float *dx;
+    SceneTier tier;   // which scenes this launch serves (ragged batches: sorted, walked boustrophedon)
+    int Vl;           // LDS geometry of the launch: >= every V_n of the tier; 0 = V
     const float *da0; // non-null: the TXP chain ran in txp_bwd_wave_kernel; d(block output) comes from here
     int debug_skip;   // timing-only diagnostic (STG_DEBUG_SKIP): 1 wgrad, 2 dgrad, 4 st_gcn -- wrong results
 };
@@ -44,6 +46,8 @@ struct BwdArgs {
 struct WgradArgs {
     ModelLayout lay;
     const int32_t *num_peds;
+    const int32_t *order;  // non-null: scenes sorted by crowd size (descending)
+    int serpentine;        // walk the sorted list boustrophedon (1) or with a plain stride (0)
     int N, V;
     const float *dy, *ws, *dzg;
     int64_t ws_stride;
@@ -516,14 +520,15 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
     constexpr int C = Cfg::C, T = Cfg::T, P = Cfg::P, NT = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int V = a.V, tid = threadIdx.x;
+    const int Vl = a.Vl > 0 ? a.Vl : V;               // LDS image sized for the largest scene of this launch's tier
     const ModelLayout &L = a.lay;
-    const int scmax = txp_sc(V);
+    const int scmax = txp_sc(Vl);
     const int plane_floats = P * scmax;
     // st_gcn phase needs 3 planes: h1 [C][T+2][V], dh2 [C][T+2][V], db1 [C][T][V]
     const bool lean = a.da0 != nullptr && a.dx == nullptr && L.n_blocks == 1;    // blocks only, no dx
-    const int st_floats = lean ? 2 * C * (T + 2) * V : (2 * C * (T + 2) + C * T) * V;
+    const int st_floats = lean ? 2 * C * (T + 2) * Vl : (2 * C * (T + 2) + C * T) * Vl;
     const int reg_floats = lean ? st_floats : (plane_floats > st_floats ? plane_floats : st_floats);
-    const int dcur_floats = lean ? C * T * V : P * C * V;
+    const int dcur_floats = lean ? C * T * Vl : P * C * Vl;
     const int n_small = L.n_blk_params + L.n_txp;
     float *gsm = sm;                                  // [n_small] block parameters, then the PReLU slopes
     float *dzb = gsm + ((n_small + 3) & ~3);          // [P][SC]   dz_l, zero-bordered (aliases the st_gcn planes)
@@ -535,7 +540,13 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
 
     for (int e = tid; e < n_small; e += NT) gsm[e] = 0.f;
 
-    for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
+    int t_begin, t_end;
+    tier_range(a.tier, a.N, V, t_begin, t_end);
+    const int M = t_end - t_begin;
+    for (int r = 0; r * (int)gridDim.x < M; ++r) {
+        const int it = walk_item(r, blockIdx.x, gridDim.x, M, a.tier.order != nullptr && a.tier.serpentine);
+        if (it < 0) continue;
+        const int n = a.tier.order ? a.tier.order[t_begin + it] : it;
         int vi = a.num_peds ? a.num_peds[n] : V;
         vi = vi < 0 ? 0 : (vi > V ? V : vi);
         float *dxn = a.dx ? a.dx + (int64_t)n * L.blk[0].cin * T * V : nullptr;
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
         }
         // ---- st_gcn blocks, last to first ------------------------------------------------------
         // lean image: db1 reuses the du plane (dcur), which is dead once dh2 / dr have been formed
-        float *H1 = dzb, *DH2 = dzb + C * (T + 2) * V, *DB1 = lean ? dcur : DH2 + C * (T + 2) * V;
+        float *H1 = dzb, *DH2 = dzb + C * (T + 2) * Vl, *DB1 = lean ? dcur : DH2 + C * (T + 2) * Vl;
         for (int j = L.n_blocks - 1; j >= 0 && !(a.debug_skip & 4); --j) {
             const float *xin = j > 0 ? wsn + L.ws_hdr_floats + (int64_t)L.blk[j - 1].ws_s * V : nullptr;
             if (lean) {       // x[n] was staged behind the saved arrays
@@ -761,7 +772,10 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
     // images per wave halve the residency to one wave per SIMD, and this loop needs two to hide its LDS
     // latency (measured slower, profiles/); a device-scope scene queue was slower too (dequeue latency).
     float *cur = buf0;
-    for (int n = __builtin_amdgcn_readfirstlane(row_id); n < a.N; n += nrows) {
+    for (int r = 0; r * nrows < a.N; ++r) {
+        const int it = walk_item(r, row_id, nrows, a.N, a.order != nullptr && a.serpentine);
+        if (it < 0) continue;
+        const int n = __builtin_amdgcn_readfirstlane(a.order ? a.order[it] : it);
         const int vi = wgrad_vi(a, n);
         if (vi == 0) continue;
         if (!(a.debug_skip & 64)) wgrad_stage<CINL>(a, layer, n, vi, cur, cur + pslot);
@@ -947,8 +961,7 @@ static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves, bool lean = 
 // barriers in its ~15 block reductions), more waves only when a scene's rows no longer fit one wave's registers
 static int bwd_waves(int V) { return env_waves("STG_BWD_WAVES", V <= 40 ? 1 : (V <= 80 ? 4 : 8)); }
 
-static int bwd_grid(const ModelLayout &L, int N, int V, bool lean = false) {
-    const int waves = bwd_waves(V);
+static int bwd_grid_w(const ModelLayout &L, int N, int V, int waves, bool lean) {
     const size_t lds = bwd_lds_bytes(L, V, waves, lean);
     if (lds > (size_t)kLdsBytes) return -1;
     int per_cu = (int)(kLdsBytes / lds);
@@ -961,6 +974,15 @@ static int bwd_grid(const ModelLayout &L, int N, int V, bool lean = false) {
         if (g > 0) grid = g;
     }
     return grid < N ? grid : N;
+}
+static int bwd_grid(const ModelLayout &L, int N, int V, bool lean = false) {
+    return bwd_grid_w(L, N, V, bwd_waves(V), lean);
+}
+// ragged batches padded beyond kBwdTierV: the scenes up to kBwdTierV pedestrians (most of a real batch) run in a
+// second launch with ONE wave per scene and the LDS image of V = kBwdTierV; slab rows of both launches are stacked
+constexpr int kBwdTierV = 32;
+static int bwd_grid_small(const ModelLayout &L, int N, int V, bool lean) {
+    return V > kBwdTierV ? bwd_grid_w(L, N, kBwdTierV, 1, lean) : 0;
 }
 
 // K2 launch geometry: one persistent workgroup of `waves` waves per CU slot; the chip's slots are split
@@ -1011,7 +1033,13 @@ static int64_t bwd_scratch_floats(const ModelLayout &L, int N, int V) {
         const int g2 = bwd_grid(L, N, V, true);
         if (g2 > g1) g1 = g2;
     }
-    int64_t fl = (int64_t)g1 * (L.n_blk_params + L.n_txp);
+    int gs = bwd_grid_small(L, N, V, false);
+    if (txp_wave_fits(L, V)) {
+        const int gs2 = bwd_grid_small(L, N, V, true);
+        if (gs2 > gs) gs = gs2;
+    }
+    if (gs < 0) gs = 0;
+    int64_t fl = (int64_t)(g1 + gs) * (L.n_blk_params + L.n_txp);
     fl = (fl + 3) & ~(int64_t)3;
     if (L.n_txp > 0) {
         WgradGeom g;
@@ -1023,10 +1051,11 @@ static int64_t bwd_scratch_floats(const ModelLayout &L, int N, int V) {
             fl += (int64_t)N * (Cfg::C * Cfg::T * V);            // d(a_0) hand-off
             fl = (fl + 3) & ~(int64_t)3;
             fl += (int64_t)N * L.n_txp;                          // per-scene PReLU slope gradients
-            fl = ((fl + 3) & ~(int64_t)3) + 4;                   // scene queue head
+            fl = ((fl + 3) & ~(int64_t)3) + 4;                   // (reserved)
         }
     }
-    return fl;
+    fl = (fl + 3) & ~(int64_t)3;
+    return fl + order_floats(N, V);                                 // scene order of ragged batches (int32)
 }
 
 }  // namespace stg
@@ -1073,7 +1102,17 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     const int n_small = L.n_blk_params + L.n_txp;
     // scratch carve (must match bwd_scratch_floats)
     float *slab1 = scratch;
-    int64_t off = ((int64_t)grid * n_small + 3) & ~(int64_t)3;
+    int64_t off;
+    {
+        int g1 = bwd_grid(L, N, V), gs = bwd_grid_small(L, N, V, false);
+        if (txp_wave_fits(L, V)) {
+            const int g2 = bwd_grid(L, N, V, true), gs2 = bwd_grid_small(L, N, V, true);
+            if (g2 > g1) g1 = g2;
+            if (gs2 > gs) gs = gs2;
+        }
+        if (gs < 0) gs = 0;
+        off = ((int64_t)(g1 + gs) * n_small + 3) & ~(int64_t)3;
+    }
     float *slab2 = scratch + off;
     WgradGeom wg{};
     float *dzg = nullptr;
@@ -1096,11 +1135,19 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     a.x_sn = x_sn; a.x_sc = x_sc; a.x_st = x_st; a.x_sv = x_sv;
     a.adj = adj; a.a_sn = a_sn; a.num_peds = num_peds; a.N = N; a.V = V;
     a.dy = dy; a.ws = ws; a.ws_stride = ws_floats_per_scene(L, V); a.slab1 = slab1; a.dzg = dzg; a.dx = dx;
+    // ragged batch: sorted scene list at the tail of the scratch buffer (see bwd_scratch_floats)
+    int32_t *order = reinterpret_cast<int32_t *>(scratch + bwd_scratch_floats(L, N, V) - order_floats(N, V));
+    const bool sorted = launch_scene_order(num_peds, N, V, order, order + N, st);
+    int serp = 1;
+    if (const char *e = getenv("STG_WALK")) serp = atoi(e);
+    a.tier = SceneTier{sorted ? order : nullptr, sorted ? order + N : nullptr, -1, V, serp};
     if (const char *e = getenv("STG_DEBUG_SKIP")) a.debug_skip = atoi(e);
     if (wave_path) {
         TxpBwdArgs t{};
         t.lay = L; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V; t.dy = dy; t.ws = ws;
         t.ws_stride = a.ws_stride; t.dzg = dzg; t.da0 = da0; t.slopes = slopes;
+        t.tier = a.tier;
+        t.Vl = V;
         if (!(a.debug_skip & 2)) {
             const int rcw = launch_txp_bwd_wave(t, st);
             if (rcw != STG_OK) return rcw;
@@ -1114,11 +1161,37 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         if (e_ != hipSuccess) return hip_fail(e_, "stg_model_bwd: hipFuncSetAttribute");                     \
         hipLaunchKernelGGL(model_bwd_kernel<W>, dim3(grid), dim3(W * 64), lds, st, a, params);                       \
     } while (0)
-    switch (waves) {
-        case 1: STG_LAUNCH_BWD(1); break;
-        case 2: STG_LAUNCH_BWD(2); break;
-        case 4: STG_LAUNCH_BWD(4); break;
-        default: STG_LAUNCH_BWD(8); break;
+    int slab_rows = grid;
+    if (a.tier.order && bwd_grid_small(L, N, V, lean) > 0) {
+        // large scenes: `waves` per scene, slab rows [0, grid); small scenes: one wave per scene with the LDS image
+        // (and so the residency) of V = kBwdTierV, slab rows behind them
+        a.tier.v_lo = kBwdTierV;
+        switch (waves) {
+            case 1: STG_LAUNCH_BWD(1); break;
+            case 2: STG_LAUNCH_BWD(2); break;
+            case 4: STG_LAUNCH_BWD(4); break;
+            default: STG_LAUNCH_BWD(8); break;
+        }
+        STG_LAUNCH_CHECK("stg_model_bwd: K1 (large scenes)");
+        const int grid_hi = grid;
+        {
+            const int grid = bwd_grid_small(L, N, V, lean);
+            const size_t lds = bwd_lds_bytes(L, kBwdTierV, 1, lean);
+            a.Vl = kBwdTierV;
+            a.tier.v_lo = -1; a.tier.v_hi = kBwdTierV;
+            a.slab1 = slab1 + (int64_t)grid_hi * n_small;
+            STG_LAUNCH_BWD(1);
+            slab_rows = grid_hi + grid;
+        }
+        a.slab1 = slab1;
+        a.Vl = 0;
+    } else {
+        switch (waves) {
+            case 1: STG_LAUNCH_BWD(1); break;
+            case 2: STG_LAUNCH_BWD(2); break;
+            case 4: STG_LAUNCH_BWD(4); break;
+            default: STG_LAUNCH_BWD(8); break;
+        }
     }
 #undef STG_LAUNCH_BWD
     STG_LAUNCH_CHECK("stg_model_bwd: K1");
@@ -1127,14 +1200,14 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     r.slabs = scratch;
     r.grad = grad_params;
     r.n_params = L.n_params;
-    r.seg[r.n_seg++] = ReduceSeg{0, L.n_blk_params, grid, n_small, 0};
+    r.seg[r.n_seg++] = ReduceSeg{0, L.n_blk_params, slab_rows, n_small, 0};
     if (L.n_txp > 0) {
         if (wave_path)
             r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, (a.debug_skip & 2) ? 0 : N, L.n_txp, (int64_t)(slopes - scratch)};
         else
-            r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, grid, n_small, (int64_t)L.n_blk_params};
+            r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, slab_rows, n_small, (int64_t)L.n_blk_params};
         WgradArgs w{};
-        w.lay = L; w.num_peds = num_peds; w.N = N; w.V = V; w.dy = dy; w.ws = ws; w.dzg = dzg;
+        w.lay = L; w.num_peds = num_peds; w.order = a.tier.order; w.serpentine = a.tier.serpentine; w.N = N; w.V = V; w.dy = dy; w.ws = ws; w.dzg = dzg;
         w.ws_stride = a.ws_stride; w.slab2 = slab2; w.rows = wg.rows; w.debug_skip = a.debug_skip;
         for (int l = 0; l <= L.L + 1; ++l) w.wg_begin[l] = wg.wg_begin[l];
         if (!(a.debug_skip & 1)) {

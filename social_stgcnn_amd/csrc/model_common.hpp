@@ -69,4 +69,37 @@ __host__ __device__ inline int64_t ws_floats_per_scene(const ModelLayout &l, int
     return ws_plane_off(l, V, l.n_planes);
 }
 
+// ---- ragged batches: balanced static schedules ------------------------------------------------
+// The persistent kernels give worker w of G (a wave or a workgroup) the scenes of a fixed walk.  With per-scene
+// work ~ V_n a plain stride walk is as unbalanced as the batch is ragged, so when num_peds is given the entry
+// points first sort the scenes by V_n (descending, stable: `launch_scene_order`) and the workers walk the sorted
+// list boustrophedon: round r hands worker w item r*G + w (r even) or r*G + G-1-w (r odd).
+// walk_item() returns the list position of (round r, worker w), or -1 when that slot is past the end.
+__device__ __forceinline__ int walk_item(int r, int w, int G, int N, bool serpentine) {
+    const int i = r * G + ((serpentine && (r & 1)) ? G - 1 - w : w);
+    return i < N ? i : -1;
+}
+// V-tier of a launch: the scenes with v_lo < V_n <= v_hi, a contiguous range of the sorted list
+struct SceneTier {
+    const int32_t *order;      // sorted scene list or null (then the tier is the whole batch in batch order)
+    const int32_t *key_start;  // tier offsets of the sorted list (see scene_order_kernel) or null
+    int v_lo, v_hi;
+    int serpentine;            // walk the sorted list boustrophedon (1) or with a plain stride (0)
+};
+__device__ __forceinline__ void tier_range(const SceneTier &t, int N, int V, int &begin, int &end) {
+    begin = 0;
+    end = N;
+    if (t.order && t.key_start) {
+        begin = t.key_start[V - (t.v_hi > V ? V : t.v_hi)];
+        end = t.key_start[V - t.v_lo];          // v_lo = -1 -> key_start[V + 1] = N
+    }
+}
+constexpr int kOrderMaxN = 65536;      // scene_order_kernel is ONE workgroup: N/1024 scenes per lane
+constexpr int kOrderMaxV = 1023;
+// floats reserved in the scratch buffers for the scene order: N int32 + the V+2 tier offsets key_start[]
+__host__ __device__ inline int64_t order_floats(int N, int V) { return ((int64_t)N + V + 2 + 3) & ~(int64_t)3; }
+// Fills order[0..N) with the scene indices sorted by clamp(num_peds[n], 0, V) descending (stable) on `st`;
+// returns false (order untouched) when the batch is outside the kernel's limits or num_peds is null.
+bool launch_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, int32_t *key_start, hipStream_t st);
+
 }  // namespace stg

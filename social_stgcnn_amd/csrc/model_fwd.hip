@@ -28,6 +28,7 @@ struct FwdArgs {
     float *y, *ws;
     int64_t ws_stride;
     float *stats;
+    const int32_t *order;   // non-null: scenes sorted by crowd size (descending); block b takes order[b]
     float *a0g;       // non-null: blocks only -- the a_0 plane goes to a0g[n] for the wave-per-scene TXP kernel
     int debug_skip;   // timing-only diagnostic (STG_DEBUG_SKIP): 16 TXP-CNN, 32 st_gcn -- wrong results
 };
@@ -405,7 +406,8 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
     const int c_in = L.blk[0].cin;
     const int out_rows = L.n_txp > 0 ? C * P : C * T;
 
-    for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
+    for (int it = blockIdx.x; it < a.N; it += gridDim.x) {
+        const int n = a.order ? a.order[it] : it;       // largest crowds are dispatched first
         int vi = a.num_peds ? a.num_peds[n] : V;
         vi = vi < 0 ? 0 : (vi > V ? V : vi);
         float *yn = a.y + (int64_t)n * out_rows * V;
@@ -509,7 +511,9 @@ extern "C" int64_t stg_model_fwd_scratch_floats(const stg_model_desc *d, int N, 
     if (rc != STG_OK) return rc;
     if (N < 0 || V <= 0) return stg::fail(STG_EINVAL, "stg_model_fwd_scratch_floats: N=%d V=%d", N, V);
     const bool stamps = getenv("STG_STAMPS") != nullptr;
-    return stg::txp_wave_fits(l, V) ? (int64_t)N * stg::plane_slot(V) + 4 + (stamps ? (int64_t)N * 32 : 0) : 0;
+    return stg::txp_wave_fits(l, V)
+               ? (int64_t)N * stg::plane_slot(V) + 4 + stg::order_floats(N, V) + (stamps ? (int64_t)N * 32 : 0)
+               : 0;
 }
 
 extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const float *buffers, const float *x,
@@ -532,6 +536,11 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     STG_REQUIRE(!wave_path || scratch, STG_EINVAL, "stg_model_fwd: scratch (stg_model_fwd_scratch_floats) is null");
     STG_REQUIRE(!ws || (reinterpret_cast<uintptr_t>(ws) & 15) == 0, STG_EINVAL, "stg_model_fwd: ws must be 16-byte aligned");
     a.a0g = wave_path ? scratch : nullptr;
+    hipStream_t st = as_stream(stream);
+    if (wave_path) {     // ragged batch: sorted scene list behind the a_0 planes
+        int32_t *order = reinterpret_cast<int32_t *>(scratch + (int64_t)N * plane_slot(V) + 4);
+        a.order = launch_scene_order(num_peds, N, V, order, order + N, st) ? order : nullptr;
+    }
     if (const char *e = getenv("STG_DEBUG_SKIP")) a.debug_skip = atoi(e);
     int waves = V <= 12 ? 1 : (V <= 40 ? 2 : (V <= 80 ? 4 : 8));
     if (wave_path) waves = V <= 4 ? 1 : 2;     // blocks only (measured at V=32: 2 waves 74 us, 4: 79, 1: 96, 8: 172)
@@ -543,7 +552,6 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_fwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
                 kLdsBytes);
     const dim3 grid((unsigned)N);
-    hipStream_t st = as_stream(stream);
 #define STG_LAUNCH_FWD(W)                                                                                    \
     do {                                                                                                     \
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&model_fwd_kernel<W>),            \
@@ -563,7 +571,13 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         TxpFwdArgs t{};
         t.lay = a.lay; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V;
         t.a0g = scratch; t.y = y; t.ws = ws; t.ws_stride = a.ws_stride;
-        t.stamps = getenv("STG_STAMPS") ? reinterpret_cast<unsigned long long *>(scratch + (int64_t)N * plane_slot(V) + 4) : nullptr;
+        t.stamps = getenv("STG_STAMPS") ? reinterpret_cast<unsigned long long *>(scratch + (int64_t)N * plane_slot(V) + 4 + order_floats(N, V)) : nullptr;
+        int serp = 1;
+        if (const char *e = getenv("STG_WALK")) serp = atoi(e);
+        // one launch for the whole (sorted) batch: V-tiers in separate launches were measured slower -- the few
+        // large scenes of a real batch take one wave tens of microseconds each and need the small ones to overlap
+        t.tier = SceneTier{a.order, a.order ? a.order + N : nullptr, -1, V, serp};
+        t.Vl = V;
         return launch_txp_fwd_wave(t, st);
     }
     return STG_OK;

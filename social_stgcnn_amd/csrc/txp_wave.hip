@@ -277,13 +277,19 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float 
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64, 2) void txp_fwd_wave_kernel(const TxpFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int V = a.V, wave = threadIdx.x >> 6;
-    const int slot = plane_slot(V);
-    const int per_wave = 2 * slot + ((C * V + 3) & ~3);
+    const int Vl = a.Vl, wave = threadIdx.x >> 6;
+    const int slot = plane_slot(Vl);
+    const int per_wave = 2 * slot + ((C * Vl + 3) & ~3);
     float *pa = sm + wave * per_wave, *pb = pa + slot;
     unsigned *ptab = reinterpret_cast<unsigned *>(pb + slot);
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;
-    for (int n = gw; n < a.N; n += nw) {
+    int begin, end;
+    tier_range(a.tier, a.N, a.V, begin, end);
+    const int M = end - begin;
+    for (int r = 0; r * nw < M; ++r) {
+        const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
+        if (it < 0) continue;
+        const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
         txp_fwd_scene(a, n, pa, pb, ptab);
         __builtin_amdgcn_wave_barrier();
     }
@@ -415,13 +421,113 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64, 2) void txp_bwd_wave_kernel(const TxpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int V = a.V, wave = threadIdx.x >> 6;
-    const int slot = plane_slot(V);
-    const int per_wave = slot + P * C * V + ((C * V + 3) & ~3);
+    const int Vl = a.Vl, wave = threadIdx.x >> 6;
+    const int slot = plane_slot(Vl);
+    const int per_wave = slot + P * C * Vl + ((C * Vl + 3) & ~3);
     float *dzb = sm + wave * per_wave, *dcur = dzb + slot;
-    unsigned *ptab = reinterpret_cast<unsigned *>(dcur + P * C * V);
+    unsigned *ptab = reinterpret_cast<unsigned *>(dcur + P * C * Vl);
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;
-    for (int n = gw; n < a.N; n += nw) {
+    int begin, end;
+    tier_range(a.tier, a.N, a.V, begin, end);
+    const int M = end - begin;
+    for (int r = 0; r * nw < M; ++r) {
+        const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
+        if (it < 0) continue;
+        const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
+        txp_bwd_scene(a, n, dzb, dcur, ptab);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// mixed-V launch: class assignment of a workgroup (see MixGeom)
+// ------------------------------------------------------------------------------------------
+struct MixSlot {
+    int begin, end;        // this class's range of the sorted scene list
+    int worker, nworkers;  // this wave's place among the class's active waves
+    int region;            // LDS floats of this wave's private region
+    int vc;                // largest crowd of the class (LDS geometry of its scenes)
+    bool active;
+};
+
+__device__ __forceinline__ MixSlot mix_assign(const SceneTier &t, const MixGeom &g, int N, int V) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t *ks = t.key_start;
+    // summed crowd size (+ a per-scene constant) of the three classes, keys spread over the lanes
+    float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+    for (int k = lane; k <= V; k += 64) {
+        const int v = V - k;
+        const float w = (float)(ks[k + 1] - ks[k]) * (float)(v + 4);
+        if (v <= g.v_small) w0 += w;
+        else if (v <= g.v_mid) w1 += w;
+        else w2 += w;
+    }
+    w0 = wave_sum(w0);
+    w1 = wave_sum(w1);
+    w2 = wave_sum(w2);
+    const int s0 = ks[V - g.v_small];                       // first scene with V_n <= v_small
+    const int s1 = ks[V - (g.v_mid < V ? g.v_mid : V)];     // first scene with V_n <= v_mid
+    // workgroup-time of a class = work / active waves per workgroup (4, 2, 1)
+    const float t0 = w0 * 0.25f, t1 = w1 * 0.5f, t2 = w2;
+    const float tt = t0 + t1 + t2;
+    const int G = gridDim.x;
+    int g2 = s1 > 0 ? (int)((float)G * t2 / tt) : 0;
+    int g1 = s0 > s1 ? (int)((float)G * t1 / tt) : 0;
+    if (s1 > 0 && g2 < 1) g2 = 1;
+    if (s0 > s1 && g1 < 1) g1 = 1;
+    if (g2 > s1) g2 = s1;                                   // never more workgroups than scenes
+    if (g1 * 2 > s0 - s1 + 1) g1 = (s0 - s1 + 1) >> 1;
+    int g0 = G - g1 - g2;
+    while (g0 < 1 && s0 < N) {                              // the small class must keep a workgroup (G >= 4)
+        if (g2 > 1 && g2 >= g1) --g2;
+        else if (g1 > 1) --g1;
+        else break;
+        g0 = G - g1 - g2;
+    }
+    const int b = blockIdx.x;
+    MixSlot m;
+    int aw, j, gc;
+    if (b < g2) { aw = 1; j = b; gc = g2; m.begin = 0; m.end = s1; m.vc = V; }
+    else if (b < g2 + g1) { aw = 2; j = b - g2; gc = g1; m.begin = s1; m.end = s0; m.vc = g.v_mid < V ? g.v_mid : V; }
+    else { aw = 4; j = b - g2 - g1; gc = g0; m.begin = s0; m.end = N; m.vc = g.v_small; }
+    m.active = wave < aw;
+    m.worker = j * aw + wave;
+    m.nworkers = gc * aw;
+    m.region = g.block_floats / aw;
+    return m;
+}
+
+__global__ __launch_bounds__(256, 2) void txp_fwd_wave_mixed_kernel(const TxpFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const MixSlot m = mix_assign(a.tier, a.mix, a.N, a.V);
+    if (!m.active) return;
+    const int wave = threadIdx.x >> 6;
+    const int slot = plane_slot(m.vc);                  // region = [plane | plane | ptab] of the class's largest scene
+    float *pa = sm + wave * m.region, *pb = pa + slot;
+    unsigned *ptab = reinterpret_cast<unsigned *>(pb + slot);
+    const int M = m.end - m.begin;
+    for (int r = 0; r * m.nworkers < M; ++r) {
+        const int it = walk_item(r, m.worker, m.nworkers, M, a.tier.serpentine);
+        if (it < 0) continue;
+        const int n = __builtin_amdgcn_readfirstlane(a.tier.order[m.begin + it]);
+        txp_fwd_scene(a, n, pa, pb, ptab);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void txp_bwd_wave_mixed_kernel(const TxpBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const MixSlot m = mix_assign(a.tier, a.mix, a.N, a.V);
+    if (!m.active) return;
+    const int wave = threadIdx.x >> 6;
+    const int slot = plane_slot(m.vc);                  // region = [dz plane | dcur | ptab] of the class's largest scene
+    float *dzb = sm + wave * m.region, *dcur = dzb + slot;
+    unsigned *ptab = reinterpret_cast<unsigned *>(dcur + P * C * m.vc);
+    const int M = m.end - m.begin;
+    for (int r = 0; r * m.nworkers < M; ++r) {
+        const int it = walk_item(r, m.worker, m.nworkers, M, a.tier.serpentine);
+        if (it < 0) continue;
+        const int n = __builtin_amdgcn_readfirstlane(a.tier.order[m.begin + it]);
         txp_bwd_scene(a, n, dzb, dcur, ptab);
         __builtin_amdgcn_wave_barrier();
     }
@@ -466,8 +572,45 @@ bool txp_wave_fits(const ModelLayout &L, int V) {
     return fwd <= 48 * 1024;        // at least three waves per CU
 }
 
-int launch_txp_fwd_wave(const TxpFwdArgs &a, hipStream_t st) {
-    const size_t per_wave = ((size_t)2 * plane_slot(a.V) + ((C * a.V + 3) & ~3)) * sizeof(float);
+static size_t fwd_per_wave_floats(int v) { return (size_t)2 * plane_slot(v) + ((C * v + 3) & ~3); }
+static size_t bwd_per_wave_floats(int v) { return (size_t)plane_slot(v) + (size_t)P * C * v + ((C * v + 3) & ~3); }
+constexpr int kMixSmallV = 32;
+
+// geometry of the mixed-V launch for per-wave footprint `pw(v)`; false when the padded V does not call for it
+template <typename F>
+static bool mix_geom(F pw, int V, bool sorted, MixGeom *g) {
+    g->on = 0;
+    if (getenv("STG_NO_MIX") && atoi(getenv("STG_NO_MIX"))) return false;
+    if (!sorted || V <= kMixSmallV) return false;
+    const size_t block = 4 * pw(kMixSmallV);
+    if (pw(V) > block || block * sizeof(float) > (size_t)kLdsBytes) return false;
+    int v_mid = kMixSmallV;
+    while (v_mid < V && 2 * pw(v_mid + 1) <= block) ++v_mid;
+    g->on = 1; g->v_small = kMixSmallV; g->v_mid = v_mid; g->block_floats = (int)block;
+    return true;
+}
+static int mix_grid(size_t lds_bytes, int N) {
+    int per_cu = (int)(kLdsBytes / lds_bytes);
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    int g = kNumCU * per_cu;
+    const int need = (N + 3) / 4 + 2;
+    if (g > need) g = need;
+    return g < 4 ? 4 : g;
+}
+
+int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
+    TxpFwdArgs a = a0;
+    if (mix_geom(fwd_per_wave_floats, a.V, a.tier.order && a.tier.key_start, &a.mix)) {
+        const size_t lds = (size_t)a.mix.block_floats * sizeof(float);
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_fwd_wave_mixed_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e_ != hipSuccess) return hip_fail(e_, "txp_fwd_wave_mixed: hipFuncSetAttribute");
+        hipLaunchKernelGGL(txp_fwd_wave_mixed_kernel, dim3(mix_grid(lds, a.N)), dim3(256), lds, st, a);
+        STG_LAUNCH_CHECK("txp_fwd_wave_mixed");
+        return STG_OK;
+    }
+    const size_t per_wave = ((size_t)2 * plane_slot(a.Vl) + ((C * a.Vl + 3) & ~3)) * sizeof(float);
     const int wpb = wave_wpb(per_wave);
     const size_t lds = per_wave * wpb;
     const dim3 grid(wave_grid(lds, wpb, a.N));
@@ -484,8 +627,18 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a, hipStream_t st) {
     return STG_OK;
 }
 
-int launch_txp_bwd_wave(const TxpBwdArgs &a, hipStream_t st) {
-    const size_t per_wave = ((size_t)plane_slot(a.V) + (size_t)P * C * a.V + ((C * a.V + 3) & ~3)) * sizeof(float);
+int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {
+    TxpBwdArgs a = a0;
+    if (mix_geom(bwd_per_wave_floats, a.V, a.tier.order && a.tier.key_start, &a.mix)) {
+        const size_t lds = (size_t)a.mix.block_floats * sizeof(float);
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_bwd_wave_mixed_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e_ != hipSuccess) return hip_fail(e_, "txp_bwd_wave_mixed: hipFuncSetAttribute");
+        hipLaunchKernelGGL(txp_bwd_wave_mixed_kernel, dim3(mix_grid(lds, a.N)), dim3(256), lds, st, a);
+        STG_LAUNCH_CHECK("txp_bwd_wave_mixed");
+        return STG_OK;
+    }
+    const size_t per_wave = ((size_t)plane_slot(a.Vl) + (size_t)P * C * a.Vl + ((C * a.Vl + 3) & ~3)) * sizeof(float);
     const int wpb = wave_wpb(per_wave);
     const size_t lds = per_wave * wpb;
     const dim3 grid(wave_grid(lds, wpb, a.N));

@@ -4,10 +4,24 @@
 
 namespace stg {
 
+// Mixed-V launch (ragged batches padded beyond V = 32, sorted scene list available): ONE launch of 4-wave
+// workgroups whose LDS is sized for four scenes of up to 32 pedestrians.  The workgroups split themselves (on the
+// device, from the tier offsets of the sorted list -- no host sync) into three classes: small scenes run four to a
+// workgroup, scenes up to `v_mid` two to a workgroup (two waves idle), larger ones one to a workgroup; the class
+// sizes follow the summed crowd sizes, large classes take the lowest block indices (dispatched first).
+struct MixGeom {
+    int on;               // 0: uniform launch (Vl / tier as given)
+    int v_small, v_mid;   // class bounds: V_n <= v_small | <= v_mid | <= V
+    int block_floats;     // LDS floats of one workgroup = 4 * per-wave floats at v_small
+};
+
 struct TxpFwdArgs {
     ModelLayout lay;
     const float *params;
     const int32_t *num_peds;
+    SceneTier tier;        // which scenes this launch serves (ragged batches: sorted, walked boustrophedon)
+    int Vl;                // LDS geometry of the launch: >= every V_n of the tier (<= V)
+    MixGeom mix;
     int N, V;
     const float *a0g;      // [N][plane_slot(V)] channel-major zero-bordered a_0 planes from the block kernel
     float *y;              // (N, C, P, V)
@@ -20,6 +34,9 @@ struct TxpBwdArgs {
     ModelLayout lay;
     const float *params;
     const int32_t *num_peds;
+    SceneTier tier;        // which scenes this launch serves (ragged batches: sorted, walked boustrophedon)
+    int Vl;                // LDS geometry of the launch: >= every V_n of the tier (<= V)
+    MixGeom mix;
     int N, V;
     const float *dy;       // (N, C, P, V)
     const float *ws;

@@ -399,3 +399,22 @@ def best_of_k(y, target_rel, obs_last=None, num_peds=None, k=20, noise=None, see
                                  int(seed) & 0xFFFFFFFFFFFFFFFF, n, p, v, int(k), ptr(ade), ptr(fde), stream_ptr()),
           "stg_bestofk_eval")
     return ade, fde
+
+
+def scene_order(num_peds, v):
+    """Scene indices sorted by pedestrian count (clamped to [0, v]) descending, stable: the schedule the fused
+    kernels use for ragged batches (`stg_scene_order`).  num_peds: int32 device tensor (N,).
+    Returns (order (N,), key_start (v+2,)): scenes with at most x pedestrians are order[key_start[v-x]:]."""
+    require_gpu(num_peds)
+    n = num_peds.numel()
+    peds = peds_arg(num_peds, n, num_peds.device)
+    order = torch.empty(n, device=peds.device, dtype=torch.int32)
+    key_start = torch.empty(int(v) + 2, device=peds.device, dtype=torch.int32)
+    if n < 2:
+        order.zero_()
+        key_start.fill_(n)
+        if n == 1:
+            key_start[: int(v) - max(0, min(int(v), int(peds[0]))) + 1] = 0
+        return order, key_start
+    check(lib().stg_scene_order(ptr(peds), n, int(v), ptr(order), ptr(key_start), stream_ptr()), "stg_scene_order")
+    return order, key_start

@@ -576,3 +576,60 @@ def test_empty_and_degenerate_batches(dev):
             assert _maxdiff(val.cpu().numpy(), work[k].numpy()) < 2e-6, k
         if "num_batches" in k:
             assert int(val) == 3, k                                         # only the non-empty scenes count
+
+
+@pytest.mark.parametrize("n,v", [(1, 5), (2, 3), (70, 5), (2048, 57), (5000, 200), (16384, 1023)])
+def test_scene_order_is_a_stable_descending_sort(dev, n, v):
+    """The ragged-batch schedule: stg_scene_order == stable argsort of the clamped pedestrian counts, descending."""
+    from social_stgcnn_amd import ops
+    g = torch.Generator().manual_seed(n + v)
+    peds = torch.randint(-2, v + 3, (n,), generator=g, dtype=torch.int32)
+    got, key_start = ops.scene_order(peds.to(dev), v)
+    got, key_start = got.cpu(), key_start.cpu()
+    key = peds.clamp(0, v)
+    want = torch.sort(key, descending=True, stable=True).indices.to(torch.int32)
+    assert torch.equal(got, want)
+    for k in range(v + 2):                       # key_start[k] = #scenes with more than v-k pedestrians
+        assert int(key_start[k]) == int((key > v - k).sum()), k
+
+
+def test_ragged_batch_is_order_invariant(dev):
+    """A shuffled ragged batch (internally sorted by crowd size and dealt boustrophedon to the persistent waves)
+    gives per-scene outputs identical to running every scene alone, and gradients equal to their sum."""
+    import bench
+    from social_stgcnn_amd import ops
+    counts = bench.ragged_counts(300, seed=3)
+    v = int(counts.max())
+    obs_rel, target = bench.synth_scenes(300, v, seed=3)
+    live = np.arange(v)[None, :] < counts[:, None]
+    obs_rel *= live[:, :, None, None]
+    target *= live[:, None, :, None]
+    peds = torch.from_numpy(counts).to(dev)
+    nodes, adj = ops.adj_build(torch.from_numpy(obs_rel).to(dev), peds)
+    x, tgt = nodes.permute(0, 3, 1, 2), torch.from_numpy(target).to(dev)
+    m = _model(dev, seed=5).train()
+    y, _ = m(x, adj, peds)
+    w = torch.linspace(0.5, 1.5, 300, device=dev)
+    losses, dy = ops.bivariate_nll_with_grad(y.detach(), tgt, peds, w)
+    y.backward(dy)
+    g_batch = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    # the same scenes one at a time, compact (unpadded) tensors, no ordering involved
+    m2 = _model(dev, seed=5).train()
+    for i in range(0, 300, 7):
+        c = int(counts[i])
+        yi, _ = m2(x[i:i + 1, :, :, :c], adj[i:i + 1, :, :c, :c])
+        assert float((yi[0] - y[i, :, :, :c]).abs().max()) < 2e-5, i
+        assert torch.all(y[i, :, :, c:] == 0)
+        li, dyi = ops.bivariate_nll_with_grad(yi.detach(), tgt[i:i + 1, :, :c].contiguous(), None, w[i:i + 1])
+        assert abs(float(li) - float(losses[i])) < 1e-6
+    # gradient of the whole batch == gradient with the scenes presented in sorted order (pure permutation)
+    perm = torch.argsort(peds, descending=True, stable=True)
+    m3 = _model(dev, seed=5).train()
+    y3, _ = m3(x[perm], adj[perm], peds[perm])
+    _, dy3 = ops.bivariate_nll_with_grad(y3.detach(), tgt[perm], peds[perm], w[perm])
+    y3.backward(dy3)
+    for k, p in m3.named_parameters():
+        if p.grad is None:
+            continue
+        a, b = g_batch[k], p.grad
+        assert float((a - b).abs().max()) <= 2e-5 * max(1e-3, float(b.abs().max())), k
