@@ -549,7 +549,7 @@ def test_empty_and_degenerate_batches(dev):
     y, _ = m(nodes.permute(0, 3, 1, 2), adj, peds)
     losses = bivariate_loss(y.permute(0, 2, 3, 1), tgt, peds)
     losses.sum().backward()
-    assert torch.all(y[0] == 0) and torch.all(y[2] == 0) and float(losses[0]) == 0 and float(losses[2]) == 0
+    assert torch.all(y[0] == 0) and torch.all(y[2] == 0) and float(losses[0].detach()) == 0 and float(losses[2].detach()) == 0
     # oracle on the three non-empty scenes (V = 5, 1, 3)
     keys = [k for k, _ in m.named_parameters()]
     params = {k: state0[k].clone().requires_grad_(True) for k in keys}

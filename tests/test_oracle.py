@@ -187,3 +187,46 @@ def test_best_of_k_noise_variant_is_the_sampler_variant():
     eps = torch.stack([torch.randn(p, v, 2) for _ in range(k)])
     a2, f2 = o.best_of_k_errors_noise(vp, obs, tgt, eps)
     assert a1 == a2 and f1 == f2
+
+
+def test_oracle_reproduces_the_reference_training_curve():
+    """train_curve.npz (reference train()/vald(), 6 epochs, clip 0.5, StepLR(2, 0.2)): the oracle's group step +
+    torch's own clip_grad_norm_ / StepLR walk the same curve -- first two epochs here (CPU time)."""
+    from oracle import stgcnn_oracle as o
+    g = load_golden("train_curve.npz")
+    e = load_golden("eth_test_windows.npz")
+    n_sc, bs = int(g["n_scenes"]), int(g["batch_size"])
+    starts = np.concatenate([[0], np.cumsum(e["num_peds"])])
+    scenes = []
+    for i in range(n_sc):
+        rel = e["seq_rel"][starts[i]:starts[i + 1]]                    # (V,2,20)
+        nodes, lap = o.seq_to_graph_np(rel[:, :, :8])
+        tgt = np.ascontiguousarray(np.transpose(rel[:, :, 8:], (2, 0, 1)))
+        scenes.append((torch.from_numpy(nodes).unsqueeze(0).permute(0, 3, 1, 2), torch.from_numpy(lap),
+                       torch.from_numpy(tgt)))
+    state = {k[len("before/"):]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith("before/")}
+    keys = [k for k in state if not any(s in k for s in ("running", "num_batches"))]
+    params = [torch.nn.Parameter(state[k].clone()) for k in keys]
+    for k, p in zip(keys, params):
+        state[k] = p
+    opt = torch.optim.SGD(params, lr=float(g["lr"]))
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=int(g["lr_sh_rate"]), gamma=0.2)
+    bounds = o.group_boundaries(n_sc, bs)
+    for ep in range(2):
+        loss_sum, lo = 0.0, 0
+        for b in bounds:
+            opt.zero_grad()
+            tot = 0
+            for i in range(lo, b + 1):
+                l, _ = o.scene_loss(state, *scenes[i], True)          # closing scene: forward only (BN stats)
+                if i != b:
+                    tot = tot + l
+            # train.py:58-74: the scene that closes a group is forwarded but left out of the loss
+            loss = tot / bs
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], float(g["clip_grad"]))
+            opt.step()
+            loss_sum += float(loss.detach())
+            lo = b + 1
+        assert abs(loss_sum / n_sc - float(g["train_loss"][ep])) < 2e-6, (ep, loss_sum / n_sc)
+        sched.step()
