@@ -57,6 +57,16 @@ __host__ __device__ inline int txp_sc(int vi) {
 // [(C+2)*(vi+2) padded positions][P channels] (what the weight-gradient GEMM reads conflict-free); the
 // slot is sized by the channel-major LDS form P*txp_sc(V) >= P*(C+2)*(V+2).
 __host__ __device__ inline int plane_slot(int V) { return Cfg::P * txp_sc(V); }
+// The wave-per-scene TXP FORWARD keeps ONE plane per scene and updates it in place: C + 4 row slots; a layer reads
+// its input at slot offset 2 (even layers) or 0 (odd layers) and writes row r of its output two slots away from
+// where it read row r -- towards the rows it has already consumed (even layers walk the positions upwards, odd
+// layers downwards), so no pending read ever sees a new value.  Channel stride == 16 (mod 32) as for txp_sc.
+__host__ __device__ inline int txp_sci(int vi) {
+    const int raw = (Cfg::C + 4) * (vi + 2);
+    return raw + ((16 - (raw & 31)) & 31);
+}
+// floats of the a_0 hand-off slot (block kernel -> TXP forward): T channels in the in-place layout
+__host__ __device__ inline int a0_slot(int V) { return Cfg::T * txp_sci(V); }
 // floats of one dz_l hand-off slot: position-major [C*V positions][P channels] (padded batch V)
 __host__ __device__ inline int dz_slot(int V) { return Cfg::P * Cfg::C * V; }
 

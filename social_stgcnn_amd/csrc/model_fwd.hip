@@ -33,6 +33,13 @@ struct FwdArgs {
     int debug_skip;   // timing-only diagnostic (STG_DEBUG_SKIP): 16 TXP-CNN, 32 st_gcn -- wrong results
 };
 
+// floats of the kernel's TXP plane buffer: two-plane layout [P][txp_sc(V)], or the in-place hand-off layout
+// [T][txp_sci(V)] of the wave path -- whichever is larger (the paddings to == 16 (mod 32) differ)
+__host__ __device__ inline int fwd_plane_floats(int V) {
+    const int a = Cfg::P * txp_sc(V), b = Cfg::T * txp_sci(V);
+    return a > b ? a : b;
+}
+
 template <int K, int WAVES>
 __device__ __forceinline__ void block_sum(float (&v)[K], float *red) {
 #pragma unroll
@@ -277,7 +284,9 @@ __device__ void stgcn_block_fwd(const FwdArgs &a, const float *__restrict__ P_, 
     // ---- P6: BN (tcn.3) + residual + PReLU (model.py:150-153) ------------------------------------
     {
         const float ao = P_[b.prelu_o];
-        const int SW = txp_sw(vi), SC = txp_sc(vi);
+        // plane geometry: the wave-per-scene TXP kernel takes a_0 in its in-place layout (channel stride txp_sci,
+        // `plane` already points at padded row 0 = row slot 2), the in-kernel TXP path in the two-plane layout
+        const int SW = txp_sw(vi), SC = a.a0g ? txp_sci(vi) : txp_sc(vi);
         for (int q = tid; q < cnt; q += NT) {
             const int t = q / vi, w = q - t * vi;
 #pragma unroll
@@ -395,8 +404,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
     constexpr int C = Cfg::C, T = Cfg::T, P = Cfg::P, NT = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int V = a.V, tid = threadIdx.x;
-    const int scmax = txp_sc(V);
-    const int plane_floats = P * scmax;
+    const int plane_floats = fwd_plane_floats(V);      // [P][txp_sc] or, for the wave path's hand-off, [T][txp_sci]
     const int reg_floats = plane_floats > 3 * C * T * V ? plane_floats : 3 * C * T * V;
     float *bufA = sm;
     float *reg = bufA + plane_floats;
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
                 X[e] = xn[c * a.x_sc + t * a.x_st + v * a.x_sv];
             }
             if (L.n_txp > 0)
-                for (int e = tid; e < P * SC; e += NT) bufA[e] = 0.f;
+                for (int e = tid; e < (a.a0g ? T * txp_sci(vi) : P * SC); e += NT) bufA[e] = 0.f;
         }
         __syncthreads();
         for (int j = 0; j < L.n_blocks && !(a.debug_skip & 32); ++j) {
@@ -439,25 +447,30 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
             float *yb = (last && L.n_txp == 0) ? yn : nullptr;
             if (L.blk[j].cin == Cfg::CIN0)
                 stgcn_block_fwd<Cfg::CIN0, WAVES>(a, params, buffers, L.blk[j], n, vi, X, G, H, cs, red, wsn, statn,
-                                                  last && L.n_txp > 0, bufA, yb, !last);
+                                                  last && L.n_txp > 0, a.a0g ? bufA + 2 * SW : bufA, yb, !last);
             else
                 stgcn_block_fwd<Cfg::C, WAVES>(a, params, buffers, L.blk[j], n, vi, X, G, H, cs, red, wsn, statn,
-                                               last && L.n_txp > 0, bufA, yb, !last);
+                                               last && L.n_txp > 0, a.a0g ? bufA + 2 * SW : bufA, yb, !last);
             float *tmp = X; X = H; H = tmp;      // block output becomes the next block's input
         }
         if (L.n_txp == 0 || (a.debug_skip & 16)) continue;
         if (a.a0g) {
             // hand the zero-bordered channel-major a_0 plane to txp_fwd_wave_kernel (linear 16-byte copy) and,
             // in training, save it position-major for the weight-gradient GEMM
-            float4 *dst = reinterpret_cast<float4 *>(a.a0g + (int64_t)n * plane_slot(V));
-            const float4 *src = reinterpret_cast<const float4 *>(bufA);
-            for (int e = tid; e < (P * SC) >> 2; e += NT) dst[e] = src[e];
+            // (T channels in the in-place layout of txp_wave: padded row r at row slot r + 2, zeros in the spare slots;
+            // the block wrote the plane in that layout, so this is a linear copy)
+            const int SCI = txp_sci(vi);
+            {
+                float4 *dst = reinterpret_cast<float4 *>(a.a0g + (int64_t)n * a0_slot(V));
+                const float4 *src = reinterpret_cast<const float4 *>(bufA);
+                for (int e = tid; e < (T * SCI) >> 2; e += NT) dst[e] = src[e];
+            }
             if (wsn) {
                 float *d2 = wsn + ws_plane_off(L, V, 0);
                 const int npad = (C + 2) * SW;
                 for (int e = tid; e < npad * P; e += NT) {
                     const int pos = e / P, ch = e - pos * P;
-                    d2[e] = bufA[ch * SC + pos];
+                    d2[e] = ch < T ? bufA[ch * SCI + 2 * SW + pos] : 0.f;
                 }
             }
             continue;
@@ -497,8 +510,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
 }
 
 static size_t fwd_lds_bytes(int V, int waves) {
-    const int scmax = txp_sc(V);
-    const int plane = Cfg::P * scmax;
+    const int plane = fwd_plane_floats(V);
     const int reg = plane > 3 * Cfg::C * Cfg::T * V ? plane : 3 * Cfg::C * Cfg::T * V;
     return (size_t)(plane + reg + Cfg::T * V + waves * 16 + 16) * sizeof(float);
 }
@@ -512,7 +524,7 @@ extern "C" int64_t stg_model_fwd_scratch_floats(const stg_model_desc *d, int N, 
     if (N < 0 || V <= 0) return stg::fail(STG_EINVAL, "stg_model_fwd_scratch_floats: N=%d V=%d", N, V);
     const bool stamps = getenv("STG_STAMPS") != nullptr;
     return stg::txp_wave_fits(l, V)
-               ? (int64_t)N * stg::plane_slot(V) + 4 + stg::order_floats(N, V) + (stamps ? (int64_t)N * 32 : 0)
+               ? (((int64_t)N * stg::a0_slot(V) + 3) & ~(int64_t)3) + 4 + stg::order_floats(N, V) + (stamps ? (int64_t)N * 32 : 0)
                : 0;
 }
 
@@ -538,7 +550,7 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     a.a0g = wave_path ? scratch : nullptr;
     hipStream_t st = as_stream(stream);
     if (wave_path) {     // ragged batch: sorted scene list behind the a_0 planes
-        int32_t *order = reinterpret_cast<int32_t *>(scratch + (int64_t)N * plane_slot(V) + 4);
+        int32_t *order = reinterpret_cast<int32_t *>(scratch + (((int64_t)N * a0_slot(V) + 3) & ~(int64_t)3) + 4);
         a.order = launch_scene_order(num_peds, N, V, order, order + N, st) ? order : nullptr;
     }
     if (const char *e = getenv("STG_DEBUG_SKIP")) a.debug_skip = atoi(e);
@@ -571,7 +583,7 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         TxpFwdArgs t{};
         t.lay = a.lay; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V;
         t.a0g = scratch; t.y = y; t.ws = ws; t.ws_stride = a.ws_stride;
-        t.stamps = getenv("STG_STAMPS") ? reinterpret_cast<unsigned long long *>(scratch + (int64_t)N * plane_slot(V) + 4 + order_floats(N, V)) : nullptr;
+        t.stamps = getenv("STG_STAMPS") ? reinterpret_cast<unsigned long long *>(scratch + (((int64_t)N * a0_slot(V) + 3) & ~(int64_t)3) + 4 + order_floats(N, V)) : nullptr;
         int serp = 1;
         if (const char *e = getenv("STG_WALK")) serp = atoi(e);
         // one launch for the whole (sorted) batch: V-tiers in separate launches were measured slower -- the few

@@ -81,7 +81,7 @@ struct BRegs {
 };
 
 template <int KJ>
-__device__ __forceinline__ void load_b(const float *__restrict__ plane, const TileGeom &g, int SW, int SC,
+__device__ __forceinline__ void load_b(const float *plane, const TileGeom &g, int SW, int SC,
                                        BRegs<KJ> &b) {
     const int kq = (threadIdx.x & 63) >> 4;
 #pragma unroll
@@ -110,19 +110,28 @@ __device__ __forceinline__ void mma_pair(const float (&wreg)[9 * KJ], const BReg
 
 // epi(geom, u, acc) finishes tile u of a pair.  (A software-pipelined form -- next pair's operands fetched
 // ahead, previous pair's epilogue deferred -- measured no faster and cost 100 VGPRs: tools/micro/conv_tile_bench.)
-template <int KJ, typename Epi>
+// REV walks the tile pairs from the last position down and finishes the upper tile of a pair first (the in-place
+// forward's odd layers: their writes land two rows ABOVE the rows still to be read).
+template <int KJ, bool REV = false, typename Epi>
 __device__ __forceinline__ void conv_tiles(const float (&wreg)[9 * KJ], const f32x4 binit,
-                                           const float *__restrict__ plane, const unsigned *ptab, int npos, int SW,
+                                           const float *plane, const unsigned *ptab, int npos, int SW,
                                            int SC, Epi epi) {
     const int ntiles = (npos + 15) >> 4;
-    for (int tile0 = 0; tile0 < ntiles; tile0 += 2) {
+    const int npairs = (ntiles + 1) >> 1;
+    for (int pr = 0; pr < npairs; ++pr) {
+        const int tile0 = 2 * (REV ? npairs - 1 - pr : pr);
         const TileGeom g = tile_geom(tile0, ptab, npos);
         BRegs<KJ> b;
         load_b<KJ>(plane, g, SW, SC, b);
         f32x4 c0 = binit, c1 = binit;
         mma_pair<KJ>(wreg, b, c0, c1);
-        epi(g, 0, c0);
-        epi(g, 1, c1);
+        if (REV) {
+            epi(g, 1, c1);
+            epi(g, 0, c0);
+        } else {
+            epi(g, 0, c0);
+            epi(g, 1, c1);
+        }
     }
 }
 
@@ -148,16 +157,18 @@ __device__ __forceinline__ void wave_dma(const float *__restrict__ src, float *l
 // forward
 // ------------------------------------------------------------------------------------------
 // KIND 0: layer 0 (PReLU), 1: hidden layer with residual, 2: output conv (writes y)
-template <int CINL, int KIND>
+// `in` / `out` point at padded row 0 of the layer's input / output inside the ONE in-place plane (channel stride
+// SC = txp_sci(vi)); they differ by two row slots and alias, hence no __restrict__.
+template <int CINL, int KIND, bool REV>
 __device__ __forceinline__ void fwd_layer(const float (&wreg)[CINL * 9 / 4], const float *__restrict__ bias, float alpha,
-                                          const float *__restrict__ in, float *__restrict__ out, const unsigned *ptab,
+                                          const float *in, float *out, const unsigned *ptab,
                                           int vi, int V, float *zsave, float *psave, float *yout) {
     const int kq = (threadIdx.x & 63) >> 4;
-    const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi;
+    const int SW = txp_sw(vi), SC = txp_sci(vi), npos = C * vi;
     f32x4 binit;
 #pragma unroll
     for (int r = 0; r < 4; ++r) binit[r] = kq < 3 ? bias[4 * kq + r] : 0.f;
-    conv_tiles<CINL / 4>(wreg, binit, in, ptab, npos, SW, SC, [&](const TileGeom &g, int u, const f32x4 &z) {
+    conv_tiles<CINL / 4, REV>(wreg, binit, in, ptab, npos, SW, SC, [&](const TileGeom &g, int u, const f32x4 &z) {
         if (!g.ok[u] || kq == 3) return;
         if (KIND == 2) {
             // v.view(N, C, P, V) (model.py:195): the (P, C, V) conv output IS the (C, P, V) tensor
@@ -210,21 +221,31 @@ __device__ __forceinline__ void zero_saved_borders(float *psave, int vi) {
         if (a.stamps && (threadIdx.x & 63) == 0) a.stamps[(int64_t)n * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
-__device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float *pa, float *pb, unsigned *ptab) {
+// zero one row slot (SW floats) of every channel of the in-place plane
+__device__ __forceinline__ void zero_row_slot(float *buf, int slot_row, int SW, int SC) {
+    const int lane = threadIdx.x & 63;
+    for (int e = lane; e < P * SW; e += 64) {
+        const int ch = e / SW, c = e - ch * SW;
+        buf[ch * SC + slot_row * SW + c] = 0.f;
+    }
+}
+
+__device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float *buf, unsigned *ptab) {
     const ModelLayout &L = a.lay;
     const int V = a.V, lane = threadIdx.x & 63;
-    const int slot = plane_slot(V);
     STG_STAMP(0);
     int vi = a.num_peds ? a.num_peds[n] : V;
     vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
     if (vi == 0) return;                               // (the block kernel already zero-filled y)
-    const int SC = txp_sc(vi);
+    const int SW = txp_sw(vi), SC = txp_sci(vi);
     const float *Pm = a.params;
     float *yn = a.y + (int64_t)n * (C * P) * V;
     float *wsn = a.ws ? a.ws + n * a.ws_stride : nullptr;
 
-    wave_dma(a.a0g + (int64_t)n * slot, pa, (P * SC) >> 2);
-    wave_zero(pb, (P * SC) >> 2);
+    // a_0: T channels arrive in the in-place layout (rows at slot offset 2, zeros elsewhere); channels T..P-1 start
+    // as zeros (their borders must read 0 once layer 0 has written their interiors)
+    wave_dma(a.a0g + (int64_t)n * a0_slot(V), buf, (T * SC) >> 2);
+    wave_zero(buf + T * SC, ((P - T) * SC) >> 2);
     build_ptab(ptab, vi, C * vi);
     float w0[T * 9 / 4];
     load_w_fwd<T>(Pm + L.txp_w[0], w0);
@@ -232,7 +253,7 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float 
     __builtin_amdgcn_wave_barrier();
     STG_STAMP(1);
 
-    float *in = pa, *out = pb;
+    float *hi = buf + 2 * SW, *lo = buf;            // padded row 0 of the two positions of the plane
     float wa[27], wb[27];          // two weight register sets: layer l computes from one while l+1 loads
     auto w_of = [&](int l) { return Pm + (l < L.L ? L.txp_w[l] : L.out_w); };
     auto zs_of = [&](int l) { return wsn ? wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V : nullptr; };
@@ -241,35 +262,44 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float 
         if (ps) zero_saved_borders(ps, vi);
         return ps;
     };
-    // layer 0 (weights w0 already resident); layer 1's weights load meanwhile
+    // layer 0 (weights w0 already resident): hi -> lo, upwards; layer 1's weights load meanwhile
     load_w_fwd<P>(w_of(1), wa);
     {
         float *zs = zs_of(0), *ps = ps_of(0);
-        fwd_layer<T, 0>(w0, Pm + L.txp_b[0], Pm[L.prelus], in, out, ptab, vi, V, zs, ps, nullptr);
-        float *t = in; in = out; out = t;
+        fwd_layer<T, 0, false>(w0, Pm + L.txp_b[0], Pm[L.prelus], hi, lo, ptab, vi, V, zs, ps, nullptr);
+        __builtin_amdgcn_wave_barrier();
+        zero_row_slot(buf, C + 1, SW, SC);           // lo's bottom border held hi's padded row C - 1
     }
     STG_STAMP(2);
     int l = 1;
     bool in_a = true;              // which register set holds layer l's weights
     for (; l < L.L; ++l) {
         float *zs = zs_of(l), *ps = ps_of(l);
+        const bool odd = l & 1;    // odd layers: lo -> hi, downwards; even layers: hi -> lo, upwards
         __builtin_amdgcn_wave_barrier();
+        auto run = [&](const float (&wr)[27]) {      // (register arrays: selected statically, never by reference)
+            if (odd)
+                fwd_layer<P, 1, true>(wr, Pm + L.txp_b[l], Pm[L.prelus + l], lo, hi, ptab, vi, V, zs, ps, nullptr);
+            else
+                fwd_layer<P, 1, false>(wr, Pm + L.txp_b[l], Pm[L.prelus + l], hi, lo, ptab, vi, V, zs, ps, nullptr);
+        };
         if (in_a) {
             load_w_fwd<P>(w_of(l + 1), wb);
-            fwd_layer<P, 1>(wa, Pm + L.txp_b[l], Pm[L.prelus + l], in, out, ptab, vi, V, zs, ps, nullptr);
+            run(wa);
         } else {
             load_w_fwd<P>(w_of(l + 1), wa);
-            fwd_layer<P, 1>(wb, Pm + L.txp_b[l], Pm[L.prelus + l], in, out, ptab, vi, V, zs, ps, nullptr);
+            run(wb);
         }
+        __builtin_amdgcn_wave_barrier();
+        zero_row_slot(buf, odd ? 2 : C + 1, SW, SC);   // hi's top border held lo's padded row 2 / see layer 0
         in_a = !in_a;
-        float *t = in; in = out; out = t;
         STG_STAMP(2 + l);
     }
     __builtin_amdgcn_wave_barrier();
     if (in_a)
-        fwd_layer<P, 2>(wa, Pm + L.out_b, 0.f, in, out, ptab, vi, V, nullptr, nullptr, yn);
+        fwd_layer<P, 2, false>(wa, Pm + L.out_b, 0.f, (l & 1) ? lo : hi, nullptr, ptab, vi, V, nullptr, nullptr, yn);
     else
-        fwd_layer<P, 2>(wb, Pm + L.out_b, 0.f, in, out, ptab, vi, V, nullptr, nullptr, yn);
+        fwd_layer<P, 2, false>(wb, Pm + L.out_b, 0.f, (l & 1) ? lo : hi, nullptr, ptab, vi, V, nullptr, nullptr, yn);
     STG_STAMP(8);
     (void)lane;
 }
@@ -278,10 +308,10 @@ template <int WPB>
 __global__ __launch_bounds__(WPB * 64, 2) void txp_fwd_wave_kernel(const TxpFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Vl = a.Vl, wave = threadIdx.x >> 6;
-    const int slot = plane_slot(Vl);
-    const int per_wave = 2 * slot + ((C * Vl + 3) & ~3);
-    float *pa = sm + wave * per_wave, *pb = pa + slot;
-    unsigned *ptab = reinterpret_cast<unsigned *>(pb + slot);
+    const int slot = P * txp_sci(Vl);
+    const int per_wave = slot + ((C * Vl + 3) & ~3);
+    float *pa = sm + wave * per_wave;
+    unsigned *ptab = reinterpret_cast<unsigned *>(pa + slot);
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;
     int begin, end;
     tier_range(a.tier, a.N, a.V, begin, end);
@@ -290,7 +320,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void txp_fwd_wave_kernel(const TxpFwdA
         const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
-        txp_fwd_scene(a, n, pa, pb, ptab);
+        txp_fwd_scene(a, n, pa, ptab);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -502,15 +532,15 @@ __global__ __launch_bounds__(256, 2) void txp_fwd_wave_mixed_kernel(const TxpFwd
     const MixSlot m = mix_assign(a.tier, a.mix, a.N, a.V);
     if (!m.active) return;
     const int wave = threadIdx.x >> 6;
-    const int slot = plane_slot(m.vc);                  // region = [plane | plane | ptab] of the class's largest scene
-    float *pa = sm + wave * m.region, *pb = pa + slot;
-    unsigned *ptab = reinterpret_cast<unsigned *>(pb + slot);
+    const int slot = P * txp_sci(m.vc);                 // region = [in-place plane | ptab] of the class's largest scene
+    float *pa = sm + wave * m.region;
+    unsigned *ptab = reinterpret_cast<unsigned *>(pa + slot);
     const int M = m.end - m.begin;
     for (int r = 0; r * m.nworkers < M; ++r) {
         const int it = walk_item(r, m.worker, m.nworkers, M, a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order[m.begin + it]);
-        txp_fwd_scene(a, n, pa, pb, ptab);
+        txp_fwd_scene(a, n, pa, ptab);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -572,7 +602,7 @@ bool txp_wave_fits(const ModelLayout &L, int V) {
     return fwd <= 48 * 1024;        // at least three waves per CU
 }
 
-static size_t fwd_per_wave_floats(int v) { return (size_t)2 * plane_slot(v) + ((C * v + 3) & ~3); }
+static size_t fwd_per_wave_floats(int v) { return (size_t)P * txp_sci(v) + ((C * v + 3) & ~3); }
 static size_t bwd_per_wave_floats(int v) { return (size_t)plane_slot(v) + (size_t)P * C * v + ((C * v + 3) & ~3); }
 constexpr int kMixSmallV = 32;
 
@@ -610,7 +640,7 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
         STG_LAUNCH_CHECK("txp_fwd_wave_mixed");
         return STG_OK;
     }
-    const size_t per_wave = ((size_t)2 * plane_slot(a.Vl) + ((C * a.Vl + 3) & ~3)) * sizeof(float);
+    const size_t per_wave = fwd_per_wave_floats(a.Vl) * sizeof(float);
     const int wpb = wave_wpb(per_wave);
     const size_t lds = per_wave * wpb;
     const dim3 grid(wave_grid(lds, wpb, a.N));
