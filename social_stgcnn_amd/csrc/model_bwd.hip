@@ -952,7 +952,8 @@ static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves, bool lean = 
     const int reg = lean ? st : (plane > st ? plane : st);
     const int dcur = lean ? Cfg::C * Cfg::T * V : Cfg::P * Cfg::C * V;
     const int n_small = L.n_blk_params + L.n_txp;
-    const int saved = lean ? (2 * Cfg::C + 1 + 2 * Cfg::C) * Cfg::T * V + 16 : 0;      // [ax|cs|g|h2|x] + padding (cin <= C)
+    const int cin0 = L.blk[0].cin;
+    const int saved = lean ? (cin0 + 1 + 2 * Cfg::C + cin0) * Cfg::T * V + 16 : 0;     // [ax|cs|g|h2|x] + 4-float paddings
     const size_t fl = ((n_small + 3) & ~3) + (size_t)reg + (size_t)dcur + (size_t)waves * kRedMax + kRedMax + saved;
     return fl * sizeof(float);
 }
