@@ -1212,9 +1212,6 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         w.ws_stride = a.ws_stride; w.slab2 = slab2; w.rows = wg.rows; w.debug_skip = a.debug_skip;
         for (int l = 0; l <= L.L + 1; ++l) w.wg_begin[l] = wg.wg_begin[l];
         if (!(a.debug_skip & 1)) {
-            // unused slab rows (layers with fewer workgroups than `rows`) must read as zero
-            hipError_t e0 = hipMemsetAsync(slab2, 0, sizeof(float) * wgrad_slab_base(L.L + 1, wg.rows), st);
-            if (e0 != hipSuccess) return hip_fail(e0, "stg_model_bwd: K2 slab memset");
             const dim3 g2(wg.grid);
 #define STG_LAUNCH_WG(W)                                                                                     \
     do {                                                                                                     \
@@ -1235,8 +1232,9 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         const int64_t s2 = slab2 - scratch;
         for (int l = 0; l <= L.L; ++l) {
             const int p0 = l == L.L ? L.out_w : L.txp_w[l];
-            r.seg[r.n_seg++] = ReduceSeg{p0, wgrad_row_len(l), (a.debug_skip & 1) ? 0 : wg.rows, wgrad_row_len(l),
-                                         s2 + wgrad_slab_base(l, wg.rows)};
+            // (only the rows the layer's workgroups wrote: no memset of the slab needed)
+            r.seg[r.n_seg++] = ReduceSeg{p0, wgrad_row_len(l), (a.debug_skip & 1) ? 0 : wg.wg_begin[l + 1] - wg.wg_begin[l],
+                                         wgrad_row_len(l), s2 + wgrad_slab_base(l, wg.rows)};
         }
     }
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((L.n_params + 7) / 8), dim3(256), 0, st, r);
