@@ -633,3 +633,55 @@ def test_ragged_batch_is_order_invariant(dev):
             continue
         a, b = g_batch[k], p.grad
         assert float((a - b).abs().max()) <= 2e-5 * max(1e-3, float(b.abs().max())), k
+
+
+def test_every_crowd_size_of_the_wave_path(dev):
+    """V = 1 .. 70, one launch per V holding a full scene and a ragged one (V_n = V - 1, padded): forward, loss and
+    every gradient against the fp64 oracle.  The LDS layouts pad channel strides to 16 (mod 32) in three different
+    geometries (two-plane, in-place, position-major); this walks every padding case of each."""
+    from social_stgcnn_amd import ops
+    from social_stgcnn_amd.metrics import bivariate_loss
+    O = _oracle()
+    m = _model(dev, seed=77).train()
+    state = {k: val.detach().cpu().clone() for k, val in m.state_dict().items()}
+    keys = [k for k, _ in m.named_parameters()]
+    state64 = {k: (val.double() if val.is_floating_point() else val.clone()) for k, val in state.items()}
+    worst = {}
+    for v in range(1, 71):
+        counts = [v, max(1, v - 1)]
+        rels = [_synthetic_scene(v, 1000 + 2 * v), _synthetic_scene(v, 1001 + 2 * v)]
+        rels[1][counts[1]:] = 0.0
+        params = {k: state64[k].clone().requires_grad_(True) for k in keys}
+        work = {k: (val.clone() if torch.is_tensor(val) else val) for k, val in state64.items()}
+        work.update(params)
+        ref_losses, ref_pred = [], []
+        for rel, c in zip(rels, counts):
+            nodes, lap = O.seq_to_graph_np(rel[:c, :, :8])
+            tgt, _ = O.seq_to_graph_np(rel[:c, :, 8:])
+            l, vp = O.scene_loss(work, torch.from_numpy(nodes).double().unsqueeze(0).permute(0, 3, 1, 2),
+                                 torch.from_numpy(lap).double(), torch.from_numpy(tgt).double(), True)
+            ref_losses.append(l)
+            ref_pred.append(vp.detach())
+        torch.stack(ref_losses).sum().backward()
+        with torch.no_grad():
+            m.load_state_dict(state)
+        for p in m.parameters():
+            p.grad = None
+        rel_d = torch.from_numpy(np.stack(rels)).to(dev)
+        peds = torch.tensor(counts, dtype=torch.int32, device=dev)
+        nodes_d, adj_d = ops.adj_build(rel_d[..., :8], peds)
+        tgt_d = rel_d[..., 8:].permute(0, 3, 1, 2).contiguous()
+        y, _ = m(nodes_d.permute(0, 3, 1, 2), adj_d, peds)
+        losses = bivariate_loss(y.permute(0, 2, 3, 1), tgt_d, peds)
+        losses.sum().backward()
+        for i, c in enumerate(counts):
+            err = _maxdiff(y[i, :, :, :c].detach().permute(1, 2, 0).cpu().numpy(), ref_pred[i].numpy())
+            assert err < 5e-5, (v, i, err)
+            assert torch.all(y[i, :, :, c:] == 0), (v, i)
+        assert _maxdiff(losses.detach().cpu().numpy(), torch.stack(ref_losses).detach().numpy()) < 5e-5, v
+        errs = _grad_errors(((name, p.grad) for name, p in m.named_parameters()),
+                            lambda name: None if params[name].grad is None else params[name].grad.numpy())
+        bad = {k: e for k, e in errs.items() if e > 1e-3}
+        assert not bad, (v, bad)
+        worst[v] = max(errs.values())
+    assert max(worst.values()) < 1e-3
