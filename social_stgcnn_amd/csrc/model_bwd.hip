@@ -59,7 +59,15 @@ struct WgradArgs {
 
 // slab geometry of K2: layer 0 has c_in = T, layers 1..L (L = output conv) have c_in = P
 // floats of one wave-private LDS image of K2: a staged scene (plane + dz), and at the end one slab row
-__host__ __device__ inline int wgrad_image_floats(int V) {
+// K2 stages at most kWgradChunkV pedestrian columns of a scene at a time: a larger scene is cut into
+// ceil(V_n / kWgradChunkV) equal column chunks (each with its two halo columns of the plane), every chunk one work
+// item whose LDS image -- and MFMA loop -- is that of a small scene.  The weight gradient is a sum over positions,
+// so chunks simply add.  Keeps the image at 19 KB per wave (8 waves per CU) for every V.
+constexpr int kWgradChunkV = 32;
+__host__ __device__ inline int wgrad_chunks(int V) { return (V + kWgradChunkV - 1) / kWgradChunkV; }
+__host__ __device__ inline int wgrad_image_v(int V) { return V < kWgradChunkV ? V : kWgradChunkV; }
+__host__ __device__ inline int wgrad_image_floats(int V0) {
+    const int V = wgrad_image_v(V0);
     const int img = plane_slot(V) + dz_slot(V);
     const int row = (Cfg::P * Cfg::P * 9 + Cfg::P + 3) & ~3;
     return img > row ? img : row;
@@ -705,19 +713,27 @@ __device__ __forceinline__ void wave_dma_copy(const float *__restrict__ src, flo
     }
 }
 
-// stage scene n of `layer` into one wave-private LDS image: a_l (zero-bordered, position-major
-// [(C+2)*SW][P]) and dz_l (position-major [pos][P]); LDS-DMA where the source is linear (caller waits vmcnt(0))
+// stage columns [w0, w0 + vc) of scene n of `layer` into one wave-private LDS image: a_l (zero-bordered,
+// position-major [(C+2)*(vc+2)][P], i.e. with the two halo columns) and dz_l (position-major [C*vc][P]); LDS-DMA
+// where the source is linear (caller waits vmcnt(0)).  vc == vi (w0 = 0) is the whole scene: one linear copy each.
 template <int CINL>
-__device__ __forceinline__ void wgrad_stage(const WgradArgs &a, int layer, int n, int vi, float *plane, float *dzs) {
+__device__ __forceinline__ void wgrad_stage(const WgradArgs &a, int layer, int n, int vi, int w0, int vc, float *plane,
+                                            float *dzs) {
     constexpr int C = Cfg::C, P = Cfg::P;
     const ModelLayout &L = a.lay;
     const int V = a.V, lane = threadIdx.x & 63;
-    const int SW = txp_sw(vi), npos = C * vi;
+    const int SW = txp_sw(vi), SWc = txp_sw(vc), npos = C * vc;
     const float *wsn = a.ws + n * a.ws_stride;
-    wave_dma_copy(wsn + ws_plane_off(L, V, layer), plane, ((C + 2) * SW * P + 3) >> 2);
+    const float *pl = wsn + ws_plane_off(L, V, layer);
+    if (vc == vi) {
+        wave_dma_copy(pl, plane, ((C + 2) * SW * P + 3) >> 2);
+    } else {
+        for (int r = 0; r < C + 2; ++r)               // row r, padded columns w0 .. w0 + vc + 1
+            wave_dma_copy(pl + (int64_t)(r * SW + w0) * P, plane + r * SWc * P, (SWc * P) >> 2);
+    }
     if (layer == L.L) {
         // the output conv's dz is dy itself: (C*P) rows of V floats, vi valid -> position-major [pos][P]
-        const float *dyn = a.dy + (int64_t)n * (C * P) * V;
+        const float *dyn = a.dy + (int64_t)n * (C * P) * V + w0;
         constexpr int U = 8;
         for (int e0 = lane; e0 < P * npos; e0 += 64 * U) {
             float dv[U];
@@ -725,7 +741,7 @@ __device__ __forceinline__ void wgrad_stage(const WgradArgs &a, int layer, int n
             for (int u = 0; u < U; ++u) {
                 const int e = e0 + 64 * u;
                 const int ec = e < P * npos ? e : 0;
-                const int row = ec / vi, w = ec - row * vi;        // row = co*C + h
+                const int row = ec / vc, w = ec - row * vc;        // row = co*C + h
                 dv[u] = dyn[(int64_t)row * V + w];
             }
 #pragma unroll
@@ -738,7 +754,13 @@ __device__ __forceinline__ void wgrad_stage(const WgradArgs &a, int layer, int n
             }
         }
     } else {
-        wave_dma_copy(a.dzg + ((int64_t)n * L.L + layer) * dz_slot(V), dzs, (P * npos) >> 2);
+        const float *dz = a.dzg + ((int64_t)n * L.L + layer) * dz_slot(V);
+        if (vc == vi) {
+            wave_dma_copy(dz, dzs, (P * npos) >> 2);
+        } else {
+            for (int h = 0; h < C; ++h)
+                wave_dma_copy(dz + (int64_t)(h * vi + w0) * P, dzs + h * vc * P, (vc * P) >> 2);
+        }
     }
 }
 
@@ -754,7 +776,8 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
     const int V = a.V, lane = threadIdx.x & 63;
     const int nq = lane & 15, kq = lane >> 4;
     const int co_a = nq < P ? nq : P - 1;          // rows 12..15 of the tile are never written back
-    const int pslot = plane_slot(V);
+    const int pslot = plane_slot(wgrad_image_v(V));
+    const int nch = wgrad_chunks(V), items = a.N * nch;
     int bcol[NTILE];
     bool bone[NTILE];
 #pragma unroll
@@ -772,13 +795,17 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
     // images per wave halve the residency to one wave per SIMD, and this loop needs two to hide its LDS
     // latency (measured slower, profiles/); a device-scope scene queue was slower too (dequeue latency).
     float *cur = buf0;
-    for (int r = 0; r * nrows < a.N; ++r) {
-        const int it = walk_item(r, row_id, nrows, a.N, a.order != nullptr && a.serpentine);
+    for (int r = 0; r * nrows < items; ++r) {
+        const int it = walk_item(r, row_id, nrows, items, a.order != nullptr && a.serpentine);
         if (it < 0) continue;
-        const int n = __builtin_amdgcn_readfirstlane(a.order ? a.order[it] : it);
-        const int vi = wgrad_vi(a, n);
-        if (vi == 0) continue;
-        if (!(a.debug_skip & 64)) wgrad_stage<CINL>(a, layer, n, vi, cur, cur + pslot);
+        const int si = it / nch, chunk = it - si * nch;               // work item = (scene, column chunk)
+        const int n = __builtin_amdgcn_readfirstlane(a.order ? a.order[si] : si);
+        const int vfull = wgrad_vi(a, n);
+        const int nc = wgrad_chunks(vfull);
+        if (vfull == 0 || chunk >= nc) continue;
+        const int wc = (vfull + nc - 1) / nc, w0 = chunk * wc;         // equal chunks
+        const int vi = (vfull - w0) < wc ? (vfull - w0) : wc;          // from here on: the chunk IS the scene
+        if (!(a.debug_skip & 64)) wgrad_stage<CINL>(a, layer, n, vfull, w0, vi, cur, cur + pslot);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // image of scene n complete
         __builtin_amdgcn_wave_barrier();
         const float *plane = cur, *dzs = cur + pslot;
@@ -1010,7 +1037,7 @@ static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
     }
     const int nl = L.L + 1;
     if (total < nl) total = nl;
-    const int need = (N + waves - 1) / waves;          // never more workgroups per layer than scenes need
+    const int need = (N * wgrad_chunks(V) + waves - 1) / waves;   // never more workgroups per layer than items need
     const int wsum = 6 + 7 * (nl - 1);      // per item: same staging bytes, 5 vs 7 column tiles of MFMAs
     int begin = 0, maxw = 0;
     for (int l = 0; l < nl; ++l) {
