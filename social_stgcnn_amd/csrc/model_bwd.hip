@@ -38,6 +38,7 @@ struct BwdArgs {
     float *dx;
     SceneTier tier;   // which scenes this launch serves (ragged batches: sorted, walked boustrophedon)
     int Vl;           // LDS geometry of the launch: >= every V_n of the tier; 0 = V
+    int stage;        // lean image: 1 = the block's saved arrays [ax|cs|g|h2|x] are staged in LDS by one DMA burst
     const float *da0; // non-null: the TXP chain ran in txp_bwd_wave_kernel; d(block output) comes from here
     int debug_skip;   // timing-only diagnostic (STG_DEBUG_SKIP): 1 wgrad, 2 dgrad, 4 st_gcn -- wrong results
 };
@@ -582,11 +583,12 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
                                         wsa + (int64_t)b0.ws_h2 * V};
                 float *dsts[5] = {dcur, saved, saved + n_ax, saved + n_ax + n_cs, saved + n_ax + n_cs + n_g};
                 const int cnts[5] = {n_g >> 2, n_ax >> 2, n_cs >> 2, n_g >> 2, n_g >> 2};
+                const int kmax = (!a.stage) ? 1 : 5;
 #pragma unroll
                 for (int k = 0; k < 5; ++k)
-                    if (k % WAVES == wave) wave_dma_copy(srcs[k], dsts[k], cnts[k]);
+                    if (k < kmax && k % WAVES == wave) wave_dma_copy(srcs[k], dsts[k], cnts[k]);
                 // the (strided) block input x[n] rides along into LDS: [cin][T][vi]
-                {
+                if (a.stage) {
                     const float *xn = a.x + n * a.x_sn;
                     float *xl = saved + n_ax + n_cs + 2 * n_g;
                     for (int e = tid; e < b0.cin * T * vi; e += NT) {
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
         float *H1 = dzb, *DH2 = dzb + C * (T + 2) * Vl, *DB1 = lean ? dcur : DH2 + C * (T + 2) * Vl;
         for (int j = L.n_blocks - 1; j >= 0 && !(a.debug_skip & 4); --j) {
             const float *xin = j > 0 ? wsn + L.ws_hdr_floats + (int64_t)L.blk[j - 1].ws_s * V : nullptr;
-            if (lean) {       // x[n] was staged behind the saved arrays
+            if (lean && a.stage) {       // x[n] was staged behind the saved arrays
                 const int n_ax = (L.blk[0].cin * T * vi + 3) & ~3, n_cs = (T * vi + 3) & ~3, n_g = (C * T * vi + 3) & ~3;
                 xin = saved + n_ax + n_cs + 2 * n_g;
             }
@@ -685,10 +687,10 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
             float *dxg = j == 0 ? dxn : nullptr;
             if (L.blk[j].cin == Cfg::CIN0)
                 stgcn_block_bwd<Cfg::CIN0, WAVES>(a, params, L.blk[j], n, vi, dcur, H1, DH2, DB1, red, tot, gsm, wsn, xin,
-                                                  dxs, dxg, lean ? saved : nullptr);
+                                                  dxs, dxg, (lean && a.stage) ? saved : nullptr);
             else
                 stgcn_block_bwd<Cfg::C, WAVES>(a, params, L.blk[j], n, vi, dcur, H1, DH2, DB1, red, tot, gsm, wsn, xin, dxs,
-                                               dxg, lean ? saved : nullptr);
+                                               dxg, (lean && a.stage) ? saved : nullptr);
         }
     }
     __syncthreads();
@@ -973,14 +975,14 @@ static int env_waves(const char *name, int dflt) {
     return dflt;
 }
 
-static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves, bool lean = false) {
+static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves, bool lean = false, bool stage = true) {
     const int plane = Cfg::P * txp_sc(V);
     const int st = lean ? 2 * Cfg::C * (Cfg::T + 2) * V : (2 * Cfg::C * (Cfg::T + 2) + Cfg::C * Cfg::T) * V;
     const int reg = lean ? st : (plane > st ? plane : st);
     const int dcur = lean ? Cfg::C * Cfg::T * V : Cfg::P * Cfg::C * V;
     const int n_small = L.n_blk_params + L.n_txp;
     const int cin0 = L.blk[0].cin;
-    const int saved = lean ? (cin0 + 1 + 2 * Cfg::C + cin0) * Cfg::T * V + 16 : 0;     // [ax|cs|g|h2|x] + 4-float paddings
+    const int saved = (lean && stage) ? (cin0 + 1 + 2 * Cfg::C + cin0) * Cfg::T * V + 16 : 0;     // [ax|cs|g|h2|x] + 4-float paddings
     const size_t fl = ((n_small + 3) & ~3) + (size_t)reg + (size_t)dcur + (size_t)waves * kRedMax + kRedMax + saved;
     return fl * sizeof(float);
 }
@@ -989,8 +991,21 @@ static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves, bool lean = 
 // barriers in its ~15 block reductions), more waves only when a scene's rows no longer fit one wave's registers
 static int bwd_waves(int V) { return env_waves("STG_BWD_WAVES", V <= 40 ? 1 : (V <= 80 ? 4 : 8)); }
 
+// lean image: stage the block's saved arrays in LDS (one DMA burst instead of an HBM round trip per pass) unless
+// that costs residency -- at V = 32 the staged image admits 4 workgroups per CU, the plain one 8 = one scene per
+// workgroup in a single round (measured 66 -> 59 us)
+static bool bwd_stage(const ModelLayout &L, int V, int waves) {
+    const int by_waves = 8 / waves > 0 ? 8 / waves : 1;
+    auto residency = [&](bool st) {
+        const size_t lds = bwd_lds_bytes(L, V, waves, true, st);
+        if (lds > (size_t)kLdsBytes) return 0;
+        const int per_cu = (int)(kLdsBytes / lds);
+        return per_cu < by_waves ? per_cu : by_waves;
+    };
+    return residency(true) >= residency(false);
+}
 static int bwd_grid_w(const ModelLayout &L, int N, int V, int waves, bool lean) {
-    const size_t lds = bwd_lds_bytes(L, V, waves, lean);
+    const size_t lds = bwd_lds_bytes(L, V, waves, lean, lean && bwd_stage(L, V, waves));
     if (lds > (size_t)kLdsBytes) return -1;
     int per_cu = (int)(kLdsBytes / lds);
     const int by_waves = 8 / waves > 0 ? 8 / waves : 1;   // 256-VGPR kernel: 2 waves per SIMD
@@ -1123,7 +1138,8 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     }
     const bool lean = txp_wave_fits(L, V) && dx == nullptr && L.n_blocks == 1;
     const int waves = bwd_waves(V);
-    const size_t lds = bwd_lds_bytes(L, V, waves, lean);
+    const bool stage = lean && bwd_stage(L, V, waves);
+    const size_t lds = bwd_lds_bytes(L, V, waves, lean, stage);
     STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_bwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
                 kLdsBytes);
     const int grid = bwd_grid(L, N, V, lean);
@@ -1163,6 +1179,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     a.x_sn = x_sn; a.x_sc = x_sc; a.x_st = x_st; a.x_sv = x_sv;
     a.adj = adj; a.a_sn = a_sn; a.num_peds = num_peds; a.N = N; a.V = V;
     a.dy = dy; a.ws = ws; a.ws_stride = ws_floats_per_scene(L, V); a.slab1 = slab1; a.dzg = dzg; a.dx = dx;
+    a.stage = stage;
     // ragged batch: sorted scene list at the tail of the scratch buffer (see bwd_scratch_floats)
     int32_t *order = reinterpret_cast<int32_t *>(scratch + bwd_scratch_floats(L, N, V) - order_floats(N, V));
     const bool sorted = launch_scene_order(num_peds, N, V, order, order + N, st);
@@ -1204,8 +1221,10 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         const int grid_hi = grid;
         {
             const int grid = bwd_grid_small(L, N, V, lean);
-            const size_t lds = bwd_lds_bytes(L, kBwdTierV, 1, lean);
+            const bool stage_s = lean && bwd_stage(L, kBwdTierV, 1);
+            const size_t lds = bwd_lds_bytes(L, kBwdTierV, 1, lean, stage_s);
             a.Vl = kBwdTierV;
+            a.stage = stage_s;
             a.tier.v_lo = -1; a.tier.v_hi = kBwdTierV;
             a.slab1 = slab1 + (int64_t)grid_hi * n_small;
             STG_LAUNCH_BWD(1);
@@ -1213,6 +1232,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         }
         a.slab1 = slab1;
         a.Vl = 0;
+        a.stage = stage;
     } else {
         switch (waves) {
             case 1: STG_LAUNCH_BWD(1); break;
