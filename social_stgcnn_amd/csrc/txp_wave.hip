@@ -1,8 +1,9 @@
 // txp_wave: the TXP-CNN (model.py:187-195) forward and its input-gradient chain as WAVE-PER-SCENE
-// kernels -- the fast path for scenes whose two activation planes fit a wave-private LDS image
-// (V <= ~57).  One wave64 owns one scene-window: no workgroup barriers, no cross-wave imbalance; six to
-// eight independent waves per CU keep the four matrix pipes fed while each wave alternates between
-// its MFMA stream and its own LDS / HBM traffic.
+// kernels -- the fast path for scenes whose activation plane(s) fit a wave-private LDS image (V <= 68).
+// One wave64 owns one scene-window: no workgroup barriers, no cross-wave imbalance; eight independent waves per CU
+// (two per SIMD) keep the four matrix pipes fed while each wave alternates between its MFMA stream and its own
+// LDS / HBM traffic.  The forward keeps ONE plane and updates it in place (txp_sci, model_common.hpp); the
+// input-gradient chain holds a dz plane and the running input gradient.
 //
 // Every 3x3 conv over the (5, V) plane is an implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32):
 //   forward   out[co][pos] = b[co] + sum_{tap,ci} W[co][ci][tap] in[ci][pos+tap]
