@@ -57,7 +57,20 @@ __global__ __launch_bounds__(256) void adj_build_kernel(
                 const float *qx = px + t * V, *qy = py + t * V;
                 const float hx = qx[h], hy = qy[h];
                 double acc = 1.0;
-                for (int k = 0; k < vi; ++k)
+                int k = 0;
+                if (VEC4) {     // rows are 16-byte aligned: four neighbours per LDS read (padded slots hold (0,0))
+                    for (; k + 4 <= vi; k += 4) {
+                        const float4 x4 = *reinterpret_cast<const float4 *>(qx + k);
+                        const float4 y4 = *reinterpret_cast<const float4 *>(qy + k);
+                        const float a0 = inv_dist(hx, hy, x4.x, y4.x), a1 = inv_dist(hx, hy, x4.y, y4.y);
+                        const float a2 = inv_dist(hx, hy, x4.z, y4.z), a3 = inv_dist(hx, hy, x4.w, y4.w);
+                        acc += (double)(k + 0 != h ? a0 : 0.f);
+                        acc += (double)(k + 1 != h ? a1 : 0.f);
+                        acc += (double)(k + 2 != h ? a2 : 0.f);
+                        acc += (double)(k + 3 != h ? a3 : 0.f);
+                    }
+                }
+                for (; k < vi; ++k)
                     if (k != h) acc += (double)inv_dist(hx, hy, qx[k], qy[k]);
                 dinv[e] = (float)(1.0 / sqrt(acc));
                 diag[e] = (float)(acc - 1.0);
@@ -77,16 +90,22 @@ __global__ __launch_bounds__(256) void adj_build_kernel(
                 const float hx = qx[h], hy = qy[h];
                 const float dh = normalize ? qd[h] : 1.f;
                 float vals[4];
+                const float4 x4 = *reinterpret_cast<const float4 *>(qx + k0);
+                const float4 y4 = *reinterpret_cast<const float4 *>(qy + k0);
+                const float4 d4 = normalize ? *reinterpret_cast<const float4 *>(qd + k0) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
+                const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
+                const float dg = (normalize && h >= k0 && h < k0 + 4) ? diag[th] : 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = k0 + j;
                     float v = 0.f;
                     if (k < vi) {
                         if (k == h)
-                            v = normalize ? diag[th] * (dh * dh) : 1.f;     // same formula as off-diagonal:
+                            v = normalize ? dg * (dh * dh) : 1.f;           // same formula as off-diagonal:
                         else {                                              // V=2 rows cancel exactly like the reference's
-                            const float a = inv_dist(hx, hy, qx[k], qy[k]);
-                            v = normalize ? -(a * (dh * qd[k])) : a;   // dh*dk commutes: L is bitwise symmetric
+                            const float a = inv_dist(hx, hy, xs[j], ys[j]);
+                            v = normalize ? -(a * (dh * ds[j])) : a;   // dh*dk commutes: L is bitwise symmetric
                         }
                     }
                     vals[j] = v;
@@ -113,6 +132,96 @@ __global__ __launch_bounds__(256) void adj_build_kernel(
     }
 }
 
+// V == 32 fast path (the north-star crowd size): thread (t, h) owns ROW h of tile t.  It computes the row's 32
+// weights once, keeps them in registers across the degree barrier (the generic kernel recomputes them), scales them
+// and parks the row in an LDS tile (16-byte chunks XOR-swizzled by the row index: conflict-free although every lane
+// writes a different row); the workgroup then streams the T tiles to HBM with coalesced 16-byte stores.
+// Same operations in the same order as adj_build_kernel: bitwise identical output.
+__global__ __launch_bounds__(256) void adj_build_rows32_kernel(
+    const float *__restrict__ rel, int64_t rel_sn, int64_t rel_sv, int64_t rel_sc, int64_t rel_st,
+    const int32_t *__restrict__ num_peds, int T, int normalize, float *__restrict__ nodes,
+    float *__restrict__ adj) {
+    constexpr int V = 32;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *px = sm;                // [T][V]
+    float *py = px + T * V;        // [T][V]
+    float *dinv = py + T * V;      // [T][V]  1/sqrt(d)
+    float *tile = dinv + T * V;    // [T*V rows][V], chunk j of row e at chunk (j ^ (e & 7))
+    const int n = blockIdx.x, tid = threadIdx.x;
+    int vi = num_peds ? num_peds[n] : V;
+    vi = vi < 0 ? 0 : (vi > V ? V : vi);
+    const float *r = rel + n * rel_sn;
+    const bool dense = rel_st == 1 && rel_sc == T && rel_sv == 2 * T;
+    for (int e = tid; e < V * 2 * T; e += blockDim.x) {
+        const int t = e % T, hc = e / T, c = hc & 1, h = hc >> 1;
+        float v = 0.f;
+        if (h < vi) v = dense ? r[e] : r[h * rel_sv + c * rel_sc + t * rel_st];
+        (c ? py : px)[t * V + h] = v;
+    }
+    __syncthreads();
+    if (nodes) {
+        float2 *o = reinterpret_cast<float2 *>(nodes + (int64_t)n * T * V * 2);
+        for (int e = tid; e < T * V; e += blockDim.x) o[e] = make_float2(px[e], py[e]);
+    }
+    for (int e0 = 0; e0 < T * V; e0 += blockDim.x) {       // (T = 8: one pass)
+        const int e = e0 + tid;
+        const bool live_row = e < T * V;
+        const int ec = live_row ? e : 0;
+        const int t = ec / V, h = ec - t * V;
+        const float *qx = px + t * V, *qy = py + t * V;
+        const float hx = qx[h], hy = qy[h];
+        float a[V];
+        double acc = 1.0;
+#pragma unroll
+        for (int k4 = 0; k4 < V / 4; ++k4) {
+            const float4 x4 = *reinterpret_cast<const float4 *>(qx + 4 * k4);
+            const float4 y4 = *reinterpret_cast<const float4 *>(qy + 4 * k4);
+            const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * k4 + j;
+                const float w = (k < vi && k != h) ? inv_dist(hx, hy, xs[j], ys[j]) : 0.f;
+                a[k] = w;
+                acc += (double)w;                  // (+0.0 for the skipped entries: same sum as the generic kernel)
+            }
+        }
+        const float dh = normalize ? (float)(1.0 / sqrt(acc)) : 1.f;
+        const float dg = (float)(acc - 1.0);
+        if (normalize && live_row) dinv[ec] = dh;
+        __syncthreads();
+        if (live_row) {
+            const float *qd = dinv + t * V;
+            float4 *trow = reinterpret_cast<float4 *>(tile + ec * V);
+#pragma unroll
+            for (int k4 = 0; k4 < V / 4; ++k4) {
+                float vals[4];
+                const float4 d4 = normalize ? *reinterpret_cast<const float4 *>(qd + 4 * k4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * k4 + j;
+                    float v = 0.f;
+                    if (h < vi && k < vi) {
+                        if (k == h) v = normalize ? dg * (dh * dh) : 1.f;
+                        else v = normalize ? -(a[k] * (dh * ds[j])) : a[k];
+                    }
+                    vals[j] = v;
+                }
+                trow[k4 ^ (ec & 7)] = make_float4(vals[0], vals[1], vals[2], vals[3]);
+            }
+        }
+        __syncthreads();
+        // coalesced copy-out of the rows [e0, e0 + blockDim.x): 8 chunks per row, un-swizzled on the way
+        float4 *out4 = reinterpret_cast<float4 *>(adj + (int64_t)n * T * V * V);
+        const int rows = (T * V - e0) < (int)blockDim.x ? (T * V - e0) : (int)blockDim.x;
+        for (int f = tid; f < rows * (V / 4); f += blockDim.x) {
+            const int row = e0 + (f >> 3), p = f & 7;
+            out4[row * (V / 4) + (p ^ (row & 7))] = reinterpret_cast<const float4 *>(tile + row * V)[p];
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace stg
 
 extern "C" int stg_adj_build(const float *rel, int64_t rel_sn, int64_t rel_sv, int64_t rel_sc,
@@ -126,6 +235,20 @@ extern "C" int stg_adj_build(const float *rel, int64_t rel_sn, int64_t rel_sv, i
     STG_REQUIRE(lds <= stg::kLdsBytes, STG_ELDS, "stg_adj_build: V=%d exceeds the LDS budget", V);
     const dim3 grid((unsigned)N), block(256);
     const bool vec4 = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(adj) & 15) == 0);
+    if (vec4 && V == 32 && T * V <= 1024) {
+        const size_t lds32 = ((size_t)3 * T * V + (size_t)T * V * V) * sizeof(float);
+        if (lds32 <= (size_t)stg::kLdsBytes) {
+            if (lds32 > 48 * 1024) {
+                hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&stg::adj_build_rows32_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+                if (e_ != hipSuccess) return stg::hip_fail(e_, "stg_adj_build: hipFuncSetAttribute");
+            }
+            hipLaunchKernelGGL(stg::adj_build_rows32_kernel, grid, block, lds32, stg::as_stream(stream), rel, rel_sn,
+                               rel_sv, rel_sc, rel_st, num_peds, T, normalize, nodes, adj);
+            STG_LAUNCH_CHECK("stg_adj_build");
+            return STG_OK;
+        }
+    }
     if (vec4)
         hipLaunchKernelGGL(stg::adj_build_kernel<true>, grid, block, lds, stg::as_stream(stream), rel, rel_sn,
                            rel_sv, rel_sc, rel_st, num_peds, V, T, normalize, nodes, adj);

@@ -129,6 +129,22 @@ def test_adj_build_batched_ragged(dev):
     rel5 = torch.from_numpy(g["rel_5"]).unsqueeze(0)
     _, a5 = ops.adj_build(rel5.to(dev))
     assert _maxdiff(a5[0].cpu().numpy(), O.seq_to_graph_np(g["rel_5"])[1]) < 1e-6
+    # batch padded to exactly 32: the row-per-thread kernel -- bitwise equal to the generic kernel (same batch padded
+    # to 36), normalised and raw, garbage in the padded slots ignored
+    vs32 = [2, 17, 5, 32, 3, 8, 0, 31]
+    rel32 = torch.zeros(len(vs32), 36, 2, 8)
+    for i, v in enumerate(vs32):
+        if v in (2, 17, 5, 32, 3, 8):
+            rel32[i, :v] = torch.from_numpy(g["rel_%d" % v])
+        elif v:
+            rel32[i, :v] = torch.from_numpy(g["rel_32"])[:v]
+    rel32[:, 32:] = 7.0
+    for norm in (True, False):
+        n_a, a_a = ops.adj_build(rel32[:, :32].contiguous().to(dev), num_peds=vs32, normalize=norm)
+        n_b, a_b = ops.adj_build(rel32.to(dev), num_peds=vs32, normalize=norm)
+        assert torch.equal(a_a, a_b[:, :, :32, :32]) and torch.equal(n_a, n_b[:, :, :32])
+    assert _maxdiff(a_a[3].cpu().numpy() * 0 + ops.adj_build(rel32[3:4, :32].contiguous().to(dev))[1][0].cpu().numpy(),
+                    g["lap_32"]) < 1e-6
 
 
 # ------------------------------------------------------------------------------------------
