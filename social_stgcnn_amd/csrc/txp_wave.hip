@@ -101,12 +101,22 @@ __device__ __forceinline__ void load_b(const float *plane, const TileGeom &g, in
 }
 
 template <int KJ>
+// Two accumulators per tile (even / odd K steps, added at the end): four independent MFMA chains per pair, so a
+// dependent MFMA never issues back to back behind its producer whatever order the scheduler picks.
 __device__ __forceinline__ void mma_pair(const float (&wreg)[9 * KJ], const BRegs<KJ> &b, f32x4 &acc0, f32x4 &acc1) {
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 9 * KJ; ++k) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[k], b.v[0][k], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[k], b.v[1][k], acc1, 0, 0, 0);
+        if (k & 1) {
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[k], b.v[0][k], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[k], b.v[1][k], o1, 0, 0, 0);
+        } else {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[k], b.v[0][k], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[k], b.v[1][k], acc1, 0, 0, 0);
+        }
     }
+    acc0 += o0;
+    acc1 += o1;
 }
 
 // epi(geom, u, acc) finishes tile u of a pair.  (A software-pipelined form -- next pair's operands fetched
@@ -263,11 +273,13 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float 
         if (ps) zero_saved_borders(ps, vi);
         return ps;
     };
-    // layer 0 (weights w0 already resident): hi -> lo, upwards; layer 1's weights load meanwhile
-    load_w_fwd<P>(w_of(1), wa);
+    // layer 0 (weights w0 already resident): hi -> lo, upwards.  The next layer's weights are fetched AFTER a
+    // layer's tile loop, not during it: 27 more live registers made the compiler serialise the loop's LDS reads
+    // (one `s_waitcnt lgkmcnt(0)` per read) instead of batching them
     {
         float *zs = zs_of(0), *ps = ps_of(0);
         fwd_layer<T, 0, false>(w0, Pm + L.txp_b[0], Pm[L.prelus], hi, lo, ptab, vi, V, zs, ps, nullptr);
+        load_w_fwd<P>(w_of(1), wa);
         __builtin_amdgcn_wave_barrier();
         zero_row_slot(buf, C + 1, SW, SC);           // lo's bottom border held hi's padded row C - 1
     }
@@ -285,11 +297,11 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float 
                 fwd_layer<P, 1, false>(wr, Pm + L.txp_b[l], Pm[L.prelus + l], hi, lo, ptab, vi, V, zs, ps, nullptr);
         };
         if (in_a) {
-            load_w_fwd<P>(w_of(l + 1), wb);
             run(wa);
+            load_w_fwd<P>(w_of(l + 1), wb);
         } else {
-            load_w_fwd<P>(w_of(l + 1), wa);
             run(wb);
+            load_w_fwd<P>(w_of(l + 1), wa);
         }
         __builtin_amdgcn_wave_barrier();
         zero_row_slot(buf, odd ? 2 : C + 1, SW, SC);   // hi's top border held lo's padded row 2 / see layer 0
@@ -306,7 +318,7 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float 
 }
 
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64, 2) void txp_fwd_wave_kernel(const TxpFwdArgs a) {
+__global__ __launch_bounds__(WPB * 64, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_fwd_wave_kernel(const TxpFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Vl = a.Vl, wave = threadIdx.x >> 6;
     const int slot = P * txp_sci(Vl);
@@ -528,7 +540,7 @@ __device__ __forceinline__ MixSlot mix_assign(const SceneTier &t, const MixGeom 
     return m;
 }
 
-__global__ __launch_bounds__(256, 2) void txp_fwd_wave_mixed_kernel(const TxpFwdArgs a) {
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_fwd_wave_mixed_kernel(const TxpFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const MixSlot m = mix_assign(a.tier, a.mix, a.N, a.V);
     if (!m.active) return;
