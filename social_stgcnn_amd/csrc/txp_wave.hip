@@ -188,14 +188,20 @@ __device__ __forceinline__ void fwd_layer(const float (&wreg)[CINL * 9 / 4], con
         } else {
             const int pp = (g.hh[u] + 1) * SW + (g.ww[u] + 1);
             f32x4 av;
+            // the residual inputs first, all four in flight: `in` and `out` are one buffer (two row slots apart), so
+            // the compiler would otherwise order every read behind the previous write (read, wait, write, read, ...)
+            float res[4] = {0.f, 0.f, 0.f, 0.f};
+            if (KIND == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) res[r] = in[(4 * kq + r) * SC + pp];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int li = (4 * kq + r) * SC + pp;
-                float v = z[r] > 0.f ? z[r] : alpha * z[r];
-                if (KIND == 1) v += in[li];
-                out[li] = v;
+                const float v = (z[r] > 0.f ? z[r] : alpha * z[r]) + res[r];
                 av[r] = v;
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(4 * kq + r) * SC + pp] = av[r];
             if (zsave) {   // position-major [pos][12]: one 16-byte store per lane
                 *reinterpret_cast<f32x4 *>(zsave + g.pos[u] * P + 4 * kq) = z;
                 *reinterpret_cast<f32x4 *>(psave + pp * P + 4 * kq) = av;
@@ -349,13 +355,16 @@ __device__ __forceinline__ void dgrad_layer(const float (&wreg)[27], const float
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     conv_tiles<3>(wreg, zero, dzb, ptab, npos, SW, SC, [&](const TileGeom &g, int u, const f32x4 &acc) {
         if (!g.ok[u]) return;
+        float old[4] = {0.f, 0.f, 0.f, 0.f};
+        if (accumulate) {                       // all four reads in flight before the first write
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * kq + r < CINL) old[r] = dcur[(4 * kq + r) * npos + g.pos[u]];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ci = 4 * kq + r;
-            if (ci < CINL) {
-                const int i = ci * npos + g.pos[u];
-                dcur[i] = accumulate ? dcur[i] + acc[r] : acc[r];
-            }
+            if (ci < CINL) dcur[ci * npos + g.pos[u]] = old[r] + acc[r];
         }
     });
 }

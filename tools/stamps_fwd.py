@@ -16,8 +16,9 @@ m = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=
 for _ in range(3): m(x, adj)
 torch.cuda.synchronize()
 scr = ops.LAST_FWD_SCRATCH
-slot = 12 * 240
-st = scr[n * slot + 4: n * slot + 4 + n * 32].cpu().numpy().view(np.uint64).reshape(n, 16).astype(np.int64)
+slot = 8 * 336                       # a0_slot(32) = T * txp_sci(32)
+off = ((n * slot + 3) & ~3) + 4 + ((n + v + 2 + 3) & ~3)     # a_0 planes, pad, scene order
+st = scr[off: off + n * 32].cpu().numpy().view(np.uint64).reshape(n, 16).astype(np.int64)
 t0 = st[:, 0].min()
 print("kernel span (cycles): %d   scenes: %d" % (st[:, 8].max() - t0, n))
 d = np.diff(st[:, :9], axis=1)
