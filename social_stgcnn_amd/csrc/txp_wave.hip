@@ -22,26 +22,47 @@ namespace {
 
 constexpr int C = Cfg::C, P = Cfg::P, T = Cfg::T;
 
+// A lane's weights of one (co, ci) pair are 9 consecutive floats (the taps): two 16-byte loads + one dword per pair
+// instead of nine scattered dwords (every lane reads a different cache line, so the request count is what costs)
+struct __attribute__((packed, aligned(4))) F4U {
+    float v[4];
+};
+__device__ __forceinline__ void load_taps(const float *__restrict__ p, float (&t)[9]) {
+    const F4U a = *reinterpret_cast<const F4U *>(p), b = *reinterpret_cast<const F4U *>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        t[i] = a.v[i];
+        t[4 + i] = b.v[i];
+    }
+    t[8] = p[8];
+}
+
 // forward A operand: lane (co = l&15, kq = l>>4) of K-step (tap, j) holds W[co][4j+kq][tap]
 template <int CINL>
 __device__ __forceinline__ void load_w_fwd(const float *__restrict__ W, float (&wreg)[CINL * 9 / 4]) {
     const int lane = threadIdx.x & 63, co = lane & 15, kq = lane >> 4;
+    const int cc = co < P ? co : 0;                   // rows 12..15 of the tile are zero
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int j = 0; j < CINL / 4; ++j) {
+        float t[9];
+        load_taps(W + (cc * CINL + 4 * j + kq) * 9, t);
 #pragma unroll
-        for (int j = 0; j < CINL / 4; ++j)
-            wreg[tap * (CINL / 4) + j] = co < P ? W[(co * CINL + 4 * j + kq) * 9 + tap] : 0.f;
+        for (int tap = 0; tap < 9; ++tap) wreg[tap * (CINL / 4) + j] = co < P ? t[tap] : 0.f;
+    }
 }
 
 // input-gradient A operand: lane (ci = l&15, kq) of K-step (tap', j) holds W[4j+kq][ci][8 - tap']
 template <int CINL>
 __device__ __forceinline__ void load_w_bwd(const float *__restrict__ W, float (&wreg)[27]) {
     const int lane = threadIdx.x & 63, ci = lane & 15, kq = lane >> 4;
+    const int cc = ci < CINL ? ci : 0;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int j = 0; j < 3; ++j) {
+        float t[9];
+        load_taps(W + ((4 * j + kq) * CINL + cc) * 9, t);
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            wreg[tap * 3 + j] = ci < CINL ? W[((4 * j + kq) * CINL + ci) * 9 + (8 - tap)] : 0.f;
+        for (int tap = 0; tap < 9; ++tap) wreg[tap * 3 + j] = ci < CINL ? t[8 - tap] : 0.f;
+    }
 }
 
 // ---- tile loop ------------------------------------------------------------------------------------
@@ -241,10 +262,10 @@ __device__ __forceinline__ void zero_saved_borders(float *psave, int vi) {
 // zero one row slot (SW floats) of every channel of the in-place plane
 __device__ __forceinline__ void zero_row_slot(float *buf, int slot_row, int SW, int SC) {
     const int lane = threadIdx.x & 63;
-    for (int e = lane; e < P * SW; e += 64) {
-        const int ch = e / SW, c = e - ch * SW;
-        buf[ch * SC + slot_row * SW + c] = 0.f;
-    }
+    float *row = buf + slot_row * SW;
+#pragma unroll
+    for (int ch = 0; ch < P; ++ch)
+        for (int c = lane; c < SW; c += 64) row[ch * SC + c] = 0.f;
 }
 
 __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float *buf, unsigned *ptab) {
@@ -266,6 +287,9 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float 
     build_ptab(ptab, vi, C * vi);
     float w0[T * 9 / 4];
     load_w_fwd<T>(Pm + L.txp_w[0], w0);
+    // (while the DMA is in flight) training: the border positions of every saved plane a_1 .. a_L are zeros
+    if (wsn)
+        for (int l = 0; l < L.L; ++l) zero_saved_borders(wsn + ws_plane_off(L, V, l + 1), vi);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     STG_STAMP(1);
@@ -274,11 +298,7 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float 
     float wa[27], wb[27];          // two weight register sets: layer l computes from one while l+1 loads
     auto w_of = [&](int l) { return Pm + (l < L.L ? L.txp_w[l] : L.out_w); };
     auto zs_of = [&](int l) { return wsn ? wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V : nullptr; };
-    auto ps_of = [&](int l) {
-        float *ps = wsn ? wsn + ws_plane_off(L, V, l + 1) : nullptr;
-        if (ps) zero_saved_borders(ps, vi);
-        return ps;
-    };
+    auto ps_of = [&](int l) { return wsn ? wsn + ws_plane_off(L, V, l + 1) : nullptr; };
     // layer 0 (weights w0 already resident): hi -> lo, upwards.  The next layer's weights are fetched AFTER a
     // layer's tile loop, not during it: 27 more live registers made the compiler serialise the loop's LDS reads
     // (one `s_waitcnt lgkmcnt(0)` per read) instead of batching them

@@ -13,7 +13,12 @@ nodes, adj = ops.adj_build(torch.from_numpy(obs_rel).to(dev))
 x = nodes.permute(0, 3, 1, 2)
 torch.manual_seed(0)
 m = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3, pred_seq_len=12).to(dev).train()
-for _ in range(3): m(x, adj)
+if os.environ.get("STAMPS_EVAL"):
+    m.eval()
+    with torch.no_grad():
+        for _ in range(3): m(x, adj)
+else:
+    for _ in range(3): m(x, adj)
 torch.cuda.synchronize()
 scr = ops.LAST_FWD_SCRATCH
 slot = 8 * 336                       # a0_slot(32) = T * txp_sci(32)
@@ -32,3 +37,10 @@ for k, nm in enumerate(names2):
     print("%-12s median %7d  p10 %7d  p90 %7d cycles" % (nm, np.median(seg[:, k]), np.percentile(seg[:, k], 10), np.percentile(seg[:, k], 90)))
 life = st[:, 8] - st[:, 0]
 print("scene total  median %d cycles; start spread: p50 %d p90 %d max %d" % (np.median(life), np.percentile(st[:, 0] - t0, 50), np.percentile(st[:, 0] - t0, 90), (st[:, 0] - t0).max()))
+
+# fine stamps of layer 1 (diagnostic build): 2 -> 12 (pointer setup + saved-border zeroing), 12 -> 9 (tile loop),
+# 9 -> 10 (weight fetch issue), 10 -> 11 (border row zeroing)
+if st[:, 12].max() > 0:
+    fine = np.stack([st[:, 12] - st[:, 2], st[:, 9] - st[:, 12], st[:, 10] - st[:, 9], st[:, 11] - st[:, 10]], 1)
+    for k, nm in enumerate(["l1 setup", "l1 tiles", "l1 wfetch", "l1 zero row"]):
+        print("%-12s median %7d  p10 %7d  p90 %7d cycles" % (nm, np.median(fine[:, k]), np.percentile(fine[:, k], 10), np.percentile(fine[:, k], 90)))
