@@ -734,26 +734,28 @@ __device__ __forceinline__ void wgrad_stage(const WgradArgs &a, int layer, int n
             wave_dma_copy(pl + (int64_t)(r * SW + w0) * P, plane + r * SWc * P, (SWc * P) >> 2);
     }
     if (layer == L.L) {
-        // the output conv's dz is dy itself: (C*P) rows of V floats, vi valid -> position-major [pos][P]
+        // the output conv's dz is dy itself: (C*P) rows of V floats, vc valid from column w0 -> position-major
+        // [pos][P].  Lanes are laid over (sub-row, w) with the row length rounded up to a power of two: no division
+        // by the runtime vc
         const float *dyn = a.dy + (int64_t)n * (C * P) * V + w0;
-        constexpr int U = 8;
-        for (int e0 = lane; e0 < P * npos; e0 += 64 * U) {
+        const int vp = vc <= 1 ? 1 : (vc <= 2 ? 2 : (vc <= 4 ? 4 : (vc <= 8 ? 8 : (vc <= 16 ? 16 : (vc <= 32 ? 32 : 64)))));
+        const int sh = __builtin_ctz(vp), rpi = 64 >> sh;          // rows per 64-lane pass
+        const int sub = lane >> sh, w = lane & (vp - 1);           // (vc <= kWgradChunkV <= 64: one column block)
+        constexpr int U = 4;
+        for (int r0 = 0; r0 < C * P; r0 += rpi * U) {
             float dv[U];
+            int di[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int e = e0 + 64 * u;
-                const int ec = e < P * npos ? e : 0;
-                const int row = ec / vc, w = ec - row * vc;        // row = co*C + h
-                dv[u] = dyn[(int64_t)row * V + w];
+                const int row = r0 + u * rpi + sub;                // row = co*C + h
+                const bool ok = w < vc && row < C * P;
+                const int rc = ok ? row : 0, co = rc / C, h = rc - co * C;
+                di[u] = ok ? (h * vc + w) * P + co : -1;
+                dv[u] = ok ? dyn[(int64_t)rc * V + w] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = e0 + 64 * u;
-                if (e < P * npos) {
-                    const int co = e / npos;
-                    dzs[(e - co * npos) * P + co] = dv[u];
-                }
-            }
+            for (int u = 0; u < U; ++u)
+                if (di[u] >= 0) dzs[di[u]] = dv[u];
         }
     } else {
         const float *dz = a.dzg + ((int64_t)n * L.L + layer) * dz_slot(V);
