@@ -1195,6 +1195,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         t.ws_stride = a.ws_stride; t.dzg = dzg; t.da0 = da0; t.slopes = slopes;
         t.tier = a.tier;
         t.Vl = V;
+        t.debug_skip = a.debug_skip;
         if (!(a.debug_skip & 2)) {
             const int rcw = launch_txp_bwd_wave(t, st);
             if (rcw != STG_OK) return rcw;

@@ -412,7 +412,8 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
         const bool is_out = l == L.L;
         constexpr int U = 4;
         float slope_acc = 0.f;
-        if (is_out) {
+        if (a.debug_skip & 512) {
+        } else if (is_out) {
             // dz of the output conv is dy: (C*P) rows of V floats, vi valid -> plane interior.  Lanes are laid over
             // (sub-row, w) with the row length rounded up to a power of two: no division by the runtime vi
             // (it cost ~50 instructions per element, 30 elements per lane)
@@ -484,7 +485,8 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
             if (lane == 0) slope_row[l] = slope_acc;
         }
         __builtin_amdgcn_wave_barrier();
-        if (l == 0) {
+        if (a.debug_skip & 1024) {
+        } else if (l == 0) {
             float w8[27];
             load_w_bwd<T>(Pm + L.txp_w[0], w8);
             dgrad_layer<T>(w8, dzb, dcur, ptab, vi, false);

@@ -44,6 +44,7 @@ struct TxpBwdArgs {
     float *dzg;            // [N][L][dz_slot(V)]   dz_l of the hidden layers for the weight-gradient GEMM
     float *da0;            // [N][C*T*V]           gradient w.r.t. the st_gcn block output
     float *slopes;         // [N][n_txp]           per-scene PReLU slope gradients
+    int debug_skip;        // timing-only diagnostic (STG_DEBUG_SKIP): 512 dz build, 1024 dgrad tile loops -- wrong results
 };
 
 // true when the wave-per-scene path serves this model / V (else the workgroup-per-scene kernels run)
