@@ -726,12 +726,20 @@ __device__ __forceinline__ void wgrad_stage(const WgradArgs &a, int layer, int n
     const int V = a.V, lane = threadIdx.x & 63;
     const int SW = txp_sw(vi), SWc = txp_sw(vc), npos = C * vc;
     const float *wsn = a.ws + n * a.ws_stride;
+    // The saved plane holds the C interior rows with their border columns ([C*SW][P]): rows 1..C of the LDS image
+    // arrive by LDS-DMA (one linear copy for a whole scene; per row with the halo columns for a column chunk), the
+    // top and bottom border rows are zeroed here.
     const float *pl = wsn + ws_plane_off(L, V, layer);
+    for (int e = lane; e < 2 * SWc * 3; e += 64) {
+        const int b = e / 3, q = e - b * 3;
+        const int pos = b < SWc ? b : (C + 1) * SWc + (b - SWc);
+        *reinterpret_cast<float4 *>(plane + pos * P + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (vc == vi) {
-        wave_dma_copy(pl, plane, ((C + 2) * SW * P + 3) >> 2);
+        wave_dma_copy(pl, plane + SWc * P, (C * SW * P) >> 2);
     } else {
-        for (int r = 0; r < C + 2; ++r)               // row r, padded columns w0 .. w0 + vc + 1
-            wave_dma_copy(pl + (int64_t)(r * SW + w0) * P, plane + r * SWc * P, (SWc * P) >> 2);
+        for (int h = 0; h < C; ++h)                   // row h + 1, padded columns w0 .. w0 + vc + 1
+            wave_dma_copy(pl + (int64_t)(h * SW + w0) * P, plane + (h + 1) * SWc * P, (SWc * P) >> 2);
     }
     if (layer == L.L) {
         // the output conv's dz is dy itself: (C*P) rows of V floats, vc valid from column w0 -> position-major

@@ -465,13 +465,13 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
                 const float4 *src = reinterpret_cast<const float4 *>(bufA);
                 for (int e = tid; e < (T * SCI) >> 2; e += NT) dst[e] = src[e];
             }
-            if (wsn) {
+            if (wsn) {        // saved planes: the C interior ROWS with their two border columns, [C*SW][P]
                 float *d2 = wsn + ws_plane_off(L, V, 0);
-                const int npad = (C + 2) * SW;
-                for (int e = tid; e < npad * P; e += NT) {
-                    const int pos = e / P, ch = e - pos * P;
-                    d2[e] = ch < T ? bufA[ch * SCI + 2 * SW + pos] : 0.f;
-                }
+                for (int h = 0; h < C; ++h)
+                    for (int e = tid; e < SW * P; e += NT) {
+                        const int col = e / P, ch = e - col * P;
+                        d2[(h * SW) * P + e] = ch < T ? bufA[ch * SCI + (h + 3) * SW + col] : 0.f;
+                    }
             }
             continue;
         }
@@ -486,12 +486,12 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
         // stages back with a linear LDS-DMA copy and reads without bank conflicts
         auto save_plane = [&](const float *pl, int idx) {
             if (!wsn) return;
-            float *dst = wsn + ws_plane_off(L, V, idx);
-            const int npad = (C + 2) * SW;
-            for (int e = tid; e < npad * P; e += NT) {
-                const int pos = e / P, ch = e - pos * P;
-                dst[e] = pl[ch * SC + pos];
-            }
+            float *dst = wsn + ws_plane_off(L, V, idx);     // the C interior rows with their border columns, [C*SW][P]
+            for (int h = 0; h < C; ++h)
+                for (int e = tid; e < SW * P; e += NT) {
+                    const int col = e / P, ch = e - col * P;
+                    dst[(h * SW) * P + e] = pl[ch * SC + (h + 1) * SW + col];
+                }
         };
         save_plane(in, 0);
         for (int l = 0; l < L.L; ++l) {

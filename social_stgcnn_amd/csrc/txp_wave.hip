@@ -225,27 +225,10 @@ __device__ __forceinline__ void fwd_layer(const float (&wreg)[CINL * 9 / 4], con
             for (int r = 0; r < 4; ++r) out[(4 * kq + r) * SC + pp] = av[r];
             if (zsave) {   // position-major [pos][12]: one 16-byte store per lane
                 *reinterpret_cast<f32x4 *>(zsave + g.pos[u] * P + 4 * kq) = z;
-                *reinterpret_cast<f32x4 *>(psave + pp * P + 4 * kq) = av;
+                *reinterpret_cast<f32x4 *>(psave + (g.hh[u] * SW + g.ww[u] + 1) * P + 4 * kq) = av;   // rows 1..C of the padded plane
             }
         }
     });
-}
-
-// zero the border positions of a saved position-major plane [(C+2)*SW][P] (interiors come from the epilogue)
-__device__ __forceinline__ void zero_saved_borders(float *psave, int vi) {
-    const int lane = threadIdx.x & 63, SW = txp_sw(vi);
-    const int nb = 2 * SW + 2 * C;                  // top row, bottom row, left/right of the C inner rows
-    for (int e = lane; e < nb * 3; e += 64) {
-        const int b = e / 3, q = e - b * 3;
-        int pos;
-        if (b < SW) pos = b;
-        else if (b < 2 * SW) pos = (C + 1) * SW + (b - SW);
-        else {
-            const int k = b - 2 * SW, row = 1 + (k >> 1);
-            pos = row * SW + ((k & 1) ? SW - 1 : 0);
-        }
-        *reinterpret_cast<float4 *>(psave + pos * P + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
 }
 
 // Scenes are dealt round-robin to the persistent waves (scene = wave id, + number of waves, ...).  A
@@ -287,9 +270,13 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float 
     build_ptab(ptab, vi, C * vi);
     float w0[T * 9 / 4];
     load_w_fwd<T>(Pm + L.txp_w[0], w0);
-    // (while the DMA is in flight) training: the border positions of every saved plane a_1 .. a_L are zeros
-    if (wsn)
-        for (int l = 0; l < L.L; ++l) zero_saved_borders(wsn + ws_plane_off(L, V, l + 1), vi);
+    // (while the DMA is in flight) training: the saved planes a_1 .. a_L hold the C interior rows WITH their two border
+    // columns ([C*SW][P], what the weight-gradient GEMM stages with one linear LDS-DMA): the borders are zeros
+    if (wsn && lane < 2 * C * 3) {
+        const int b = lane / 3, q = lane - b * 3, pos = (b >> 1) * SW + ((b & 1) ? SW - 1 : 0);
+        for (int l = 0; l < L.L; ++l)
+            *reinterpret_cast<float4 *>(wsn + ws_plane_off(L, V, l + 1) + pos * P + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     STG_STAMP(1);
