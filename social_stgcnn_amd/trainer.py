@@ -77,6 +77,23 @@ def broadcast_module(model, src=0, group=None):
             dist.broadcast(t.data, src=src, group=group)
 
 
+def shard_scenes(num_peds, world, rank, balanced=True):
+    """Indices of the scenes rank `rank` of `world` takes from a global batch (data parallel over scene-windows).
+
+    balanced=False: contiguous shards.  balanced=True: per-scene work grows with the crowd size, so the scenes are
+    sorted by pedestrian count (stable, descending) and dealt to the ranks boustrophedon -- every rank gets the same
+    number of scenes (a requirement of the captured multi-rank step) and near-equal summed crowd sizes.  The last
+    len(num_peds) % world scenes are dropped (as a DistributedSampler with drop_last would)."""
+    counts = np.asarray(num_peds).reshape(-1)
+    per = len(counts) // world
+    if not balanced:
+        return np.arange(rank * per, (rank + 1) * per)
+    order = np.argsort(-counts, kind="stable")[: per * world]
+    rounds = order.reshape(per, world)
+    rounds[1::2] = rounds[1::2, ::-1]                  # odd rounds run backwards over the ranks
+    return np.sort(rounds[:, rank])
+
+
 def group_weights(n_in_group, batch_size, device=None):
     """Per-scene loss weights of one reference group (train.py:58-67): 1/batch_size for every
     scene but the one that closes the group, which gets 0."""

@@ -130,3 +130,20 @@ def test_step_lr_schedule_matches_torch():
         opt.step()
         sched.step()
         assert abs(tr.scheduler_step() - opt.param_groups[0]["lr"]) < 1e-12
+
+
+def test_balanced_scene_shards():
+    """Data-parallel sharding by crowd size: equal scene counts, disjoint, near-equal summed crowd sizes."""
+    import bench
+    from social_stgcnn_amd.trainer import shard_scenes
+    counts = bench.ragged_counts(2051, seed=5)
+    for world in (2, 8):
+        shards = [shard_scenes(counts, world, r) for r in range(world)]
+        per = len(counts) // world
+        assert all(len(s) == per for s in shards)
+        allidx = np.concatenate(shards)
+        assert len(np.unique(allidx)) == per * world
+        sums = np.array([counts[s].sum() for s in shards], dtype=np.float64)
+        assert sums.max() / sums.min() < 1.01, sums
+        plain = np.array([counts[shard_scenes(counts, world, r, balanced=False)].sum() for r in range(world)], dtype=np.float64)
+        assert sums.max() - sums.min() <= plain.max() - plain.min()
