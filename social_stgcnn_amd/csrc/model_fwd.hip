@@ -404,8 +404,13 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
     constexpr int C = Cfg::C, T = Cfg::T, P = Cfg::P, NT = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int V = a.V, tid = threadIdx.x;
-    const int plane_floats = fwd_plane_floats(V);      // [P][txp_sc] or, for the wave path's hand-off, [T][txp_sci]
-    const int reg_floats = plane_floats > 3 * C * T * V ? plane_floats : 3 * C * T * V;
+    // blocks-only mode (wave path): the plane is just the [T][txp_sci] hand-off image and X holds c_in channels --
+    // 24 KB instead of 28 KB at V = 32: six resident workgroups per CU instead of five
+    const bool slim = a.a0g != nullptr;
+    const int xin_floats = (slim ? a.lay.blk[0].cin : C) * T * V;
+    const int plane_floats = slim ? T * txp_sci(V) : fwd_plane_floats(V);
+    const int reg_floats = slim ? xin_floats + 2 * C * T * V
+                                : (plane_floats > 3 * C * T * V ? plane_floats : 3 * C * T * V);
     float *bufA = sm;
     float *reg = bufA + plane_floats;
     float *cs = reg + reg_floats;
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
         float *statn = a.stats ? a.stats + (int64_t)n * L.stat_floats : nullptr;
         const int SW = txp_sw(vi), SC = txp_sc(vi);
         __syncthreads();
-        float *X = reg, *G = reg + C * T * V, *H = reg + 2 * C * T * V;
+        float *X = reg, *G = reg + xin_floats, *H = G + C * T * V;
         // stage x[n] (strided: the caller's permute(0,3,1,2) view, train.py:48)
         {
             const float *xn = a.x + n * a.x_sn;
@@ -509,9 +514,10 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
     }
 }
 
-static size_t fwd_lds_bytes(int V, int waves) {
-    const int plane = fwd_plane_floats(V);
-    const int reg = plane > 3 * Cfg::C * Cfg::T * V ? plane : 3 * Cfg::C * Cfg::T * V;
+static size_t fwd_lds_bytes(int V, int waves, bool slim = false, int cin = Cfg::C) {
+    const int plane = slim ? Cfg::T * txp_sci(V) : fwd_plane_floats(V);
+    const int reg = slim ? (cin + 2 * Cfg::C) * Cfg::T * V
+                         : (plane > 3 * Cfg::C * Cfg::T * V ? plane : 3 * Cfg::C * Cfg::T * V);
     return (size_t)(plane + reg + Cfg::T * V + waves * 16 + 16) * sizeof(float);
 }
 
@@ -560,7 +566,7 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         const int w = atoi(e);
         if (w == 1 || w == 2 || w == 4 || w == 8) waves = w;
     }
-    const size_t lds = fwd_lds_bytes(V, waves);
+    const size_t lds = fwd_lds_bytes(V, waves, wave_path, a.lay.blk[0].cin);
     STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_fwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
                 kLdsBytes);
     const dim3 grid((unsigned)N);
