@@ -1048,7 +1048,7 @@ struct WgradGeom {
 static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
     const size_t per_wave = (size_t)wgrad_image_floats(V) * sizeof(float);
     if (per_wave > (size_t)kLdsBytes) return false;
-    int waves = env_waves("STG_WGRAD_WAVES", 4);
+    int waves = env_waves("STG_WGRAD_WAVES", 8);
     while (waves > 1 && per_wave * waves > (size_t)kLdsBytes) waves >>= 1;
     g->waves = waves;
     g->lds = per_wave * waves;
