@@ -331,7 +331,7 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float 
 }
 
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_fwd_wave_kernel(const TxpFwdArgs a) {
+__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_fwd_wave_kernel(const TxpFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Vl = a.Vl, wave = threadIdx.x >> 6;
     const int slot = P * txp_sci(Vl);
@@ -490,7 +490,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
 }
 
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64, 2) void txp_bwd_wave_kernel(const TxpBwdArgs a) {
+__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) void txp_bwd_wave_kernel(const TxpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Vl = a.Vl, wave = threadIdx.x >> 6;
     const int slot = plane_slot(Vl);
@@ -616,7 +616,7 @@ static int wave_wpb(size_t per_wave) {
     int wpb = 4;
     if (const char *e = getenv("STG_TXP_WPB")) {
         const int w = atoi(e);
-        if (w == 1 || w == 2 || w == 4) wpb = w;
+        if (w == 1 || w == 2 || w == 4 || w == 8) wpb = w;
     }
     while (wpb > 1 && per_wave * wpb > (size_t)kLdsBytes) wpb >>= 1;
     return wpb;
@@ -692,7 +692,7 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
         if (e_ != hipSuccess) return hip_fail(e_, "txp_fwd_wave: hipFuncSetAttribute");                       \
         hipLaunchKernelGGL(txp_fwd_wave_kernel<W>, grid, dim3(W * 64), lds, st, a);                           \
     } while (0)
-    if (wpb == 4) STG_L(4); else if (wpb == 2) STG_L(2); else STG_L(1);
+    if (wpb == 8) STG_L(8); else if (wpb == 4) STG_L(4); else if (wpb == 2) STG_L(2); else STG_L(1);
 #undef STG_L
     STG_LAUNCH_CHECK("txp_fwd_wave");
     return STG_OK;
@@ -720,7 +720,7 @@ int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {
         if (e_ != hipSuccess) return hip_fail(e_, "txp_bwd_wave: hipFuncSetAttribute");                       \
         hipLaunchKernelGGL(txp_bwd_wave_kernel<W>, grid, dim3(W * 64), lds, st, a);                           \
     } while (0)
-    if (wpb == 4) STG_L(4); else if (wpb == 2) STG_L(2); else STG_L(1);
+    if (wpb == 8) STG_L(8); else if (wpb == 4) STG_L(4); else if (wpb == 2) STG_L(2); else STG_L(1);
 #undef STG_L
     STG_LAUNCH_CHECK("txp_bwd_wave");
     return STG_OK;
