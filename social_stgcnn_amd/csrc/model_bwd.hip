@@ -15,9 +15,15 @@
 //  K2 txp_wgrad_kernel<W>   the TXP weight/bias gradients as ONE skinny GEMM per layer over ALL scenes:
 //        dW_l[co][ci][tap] = sum_{scene,pos} dz_l[co][pos] a_l[ci][pos+tap],  db_l = sum dz_l
 //     M = 12 out-channels (16-row tile), N = 9*c_in columns + a ones column (bias), K = every position of
-//     every scene.  Each wave owns scenes round-robin with a private LDS image (plane a_l + dz_l) and keeps
-//     the N/16 accumulator tiles in VGPRs for the whole launch -- no barriers, no atomics.
+//     every scene.  Each wave owns work items (scene, or <= 32-column chunk of a larger scene) round-robin with a
+//     private LDS image (plane a_l + dz_l) and keeps the N/16 accumulator tiles in VGPRs for the whole launch --
+//     no barriers, no atomics.
 //  reduce_slabs_kernel      sums the slab rows of K1 and K2 into the flat gradient in a fixed order.
+//
+// On the fast path (one st_gcn block, V <= 68) the TXP input-gradient chain runs wave-per-scene in
+// txp_wave.hip (B2) and K1 is launched in its lean form (B3: st_gcn blocks only, d(a_0) handed over through HBM);
+// with num_peds the scenes are sorted by crowd size first (model_common.hpp) and the small ones run in their own,
+// denser K1 launch.
 #include "model_common.hpp"
 #include "txp_wave.hpp"
 

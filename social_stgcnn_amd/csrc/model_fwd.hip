@@ -12,6 +12,9 @@
 //    of the scene, K = (tap, 4 input channels).  Weights live in VGPRs (one per K-step), the im2col
 //    B operand is one ds_read_b32 per MFMA from a zero-bordered LDS plane whose channel stride is
 //    == 16 (mod 32) dwords (conflict-free for the four K-lane groups).
+//
+// On the fast path (one st_gcn block, V <= 68) this kernel runs the block only (F1) and hands a_0 to the
+// wave-per-scene TXP kernel of txp_wave.hip (F2) in that kernel's in-place plane layout.
 #include "model_common.hpp"
 #include "txp_wave.hpp"
 
