@@ -2,7 +2,7 @@
 // whole batch at once, equal to N successive per-scene momentum updates
 //     r <- (1-m) r + m s_n ,  n = 0..N-1
 // (the reference forwards one scene at a time, train.py:173-177).  One workgroup per statistic:
-// 256 threads fold contiguous chunks of scenes, thread 0 chains the chunk results in order.
+// 256 threads fold contiguous chunks of scenes; the chunk results are composed in order by a tree.
 #include "model_common.hpp"
 
 namespace stg {
@@ -23,23 +23,41 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float *__restrict__ 
     const float keep = 1.0f - momentum;
     float acc = 0.f, dec = 1.f;
     int cnt = 0;
-    for (int n = lo; n < hi; ++n) {
-        if (num_peds && num_peds[n] <= 0) continue;
-        acc = fmaf(acc, keep, momentum * stats[(int64_t)n * stat_floats + i]);
-        dec *= keep;
-        ++cnt;
+    for (int n0 = lo; n0 < hi; n0 += 8) {            // eight loads in flight, folded in scene order
+        float sv[8];
+        bool live[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int n = n0 + u;
+            live[u] = n < hi && !(num_peds && num_peds[n] <= 0);
+            sv[u] = live[u] ? stats[(int64_t)n * stat_floats + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (live[u]) {
+                acc = fmaf(acc, keep, momentum * sv[u]);
+                dec *= keep;
+                ++cnt;
+            }
     }
     acc_s[tid] = acc;
     dec_s[tid] = dec;
     cnt_s[tid] = cnt;
     __syncthreads();
-    if (tid == 0) {
-        float r = buffers[i];
-        int total = 0;
-        for (int j = 0; j < 256; ++j) {
-            r = fmaf(r, dec_s[j], acc_s[j]);
-            total += cnt_s[j];
+    // ordered tree over the 256 chunk results: (dec, acc) pairs compose associatively,
+    // (d1, a1) then (d2, a2) = (d1 d2, a1 d2 + a2) -- eight steps instead of a 256-long serial chain
+    for (int off = 1; off < 256; off <<= 1) {
+        if ((tid & (2 * off - 1)) == 0) {
+            const float d2 = dec_s[tid + off], a2 = acc_s[tid + off];
+            acc_s[tid] = fmaf(acc_s[tid], d2, a2);
+            dec_s[tid] *= d2;
+            cnt_s[tid] += cnt_s[tid + off];
         }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float r = fmaf(buffers[i], dec_s[0], acc_s[0]);
+        const int total = cnt_s[0];
         buffers[i] = r;
         // one counter per BatchNorm: bumped by the block that owns the layer's first statistic
         if (i % (2 * Cfg::C) == 0) {
