@@ -361,19 +361,14 @@ __device__ __forceinline__ void dgrad_layer(const float (&wreg)[27], const float
     const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     conv_tiles<3>(wreg, zero, dzb, ptab, npos, SW, SC, [&](const TileGeom &g, int u, const f32x4 &acc) {
-        if (!g.ok[u]) return;
-        float old[4] = {0.f, 0.f, 0.f, 0.f};
-        if (accumulate) {                       // all four reads in flight before the first write
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * kq + r < CINL) old[r] = dcur[(4 * kq + r) * npos + g.pos[u]];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ci = 4 * kq + r;
-            if (ci < CINL) dcur[ci * npos + g.pos[u]] = old[r] + acc[r];
-        }
+        if (!g.ok[u] || 4 * kq >= CINL) return;
+        // the running input gradient is position-major [pos][P]: a lane's four channels are one 16-byte LDS access
+        f32x4 *slot = reinterpret_cast<f32x4 *>(dcur + g.pos[u] * P + 4 * kq);
+        f32x4 v = acc;
+        if (accumulate) v += *slot;
+        *slot = v;
     });
+    (void)npos;
 }
 
 __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float *dzb, float *dcur, unsigned *ptab) {
@@ -452,10 +447,11 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
                         const unsigned hw = ptab[p];
                         const int h = (int)(hw >> 16), w = (int)(hw & 0xffffu);
                         f32x4 dzv;
+                        const f32x4 dv = reinterpret_cast<const f32x4 *>(dcur)[vv];   // [pos][P]: vector vv = (p, q)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int ch = 4 * q + r;
-                            const float z = zv[u][r], d = dcur[ch * npos + p];
+                            const float z = zv[u][r], d = dv[r];
                             float dz = d;
                             if (!(z > 0.f)) {
                                 dz = alpha * d;
@@ -486,7 +482,8 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
     // dead slopes (layers >= L) and the hand-off of d(a_0) = d(block output) [C][T][vi] to the st_gcn backward
     for (int e = L.L + lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;
     float *dout = a.da0 + (int64_t)n * (C * T * V);
-    for (int e = lane; e < C * T * vi; e += 64) dout[e] = dcur[e];
+    for (int ch = 0; ch < T; ++ch)                       // [pos][P] in LDS -> [T][C*vi] (= [C][T][vi] flat) in HBM
+        for (int pos = lane; pos < npos; pos += 64) dout[ch * npos + pos] = dcur[pos * P + ch];
 }
 
 template <int WPB>
