@@ -446,8 +446,11 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
                 const int v = e % vi, ct = e / vi, t = ct % T, c = ct / T;
                 X[e] = xn[c * a.x_sc + t * a.x_st + v * a.x_sv];
             }
-            if (L.n_txp > 0)
-                for (int e = tid; e < (a.a0g ? T * txp_sci(vi) : P * SC); e += NT) bufA[e] = 0.f;
+            if (L.n_txp > 0) {                       // (both sizes are multiples of 16 floats)
+                float4 *z4 = reinterpret_cast<float4 *>(bufA);
+                for (int e = tid; e < ((a.a0g ? T * txp_sci(vi) : P * SC) >> 2); e += NT)
+                    z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         __syncthreads();
         for (int j = 0; j < L.n_blocks && !(a.debug_skip & 32); ++j) {
@@ -476,9 +479,14 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
             if (wsn) {        // saved planes: the C interior ROWS with their two border columns, [C*SW][P]
                 float *d2 = wsn + ws_plane_off(L, V, 0);
                 for (int h = 0; h < C; ++h)
-                    for (int e = tid; e < SW * P; e += NT) {
-                        const int col = e / P, ch = e - col * P;
-                        d2[(h * SW) * P + e] = ch < T ? bufA[ch * SCI + (h + 3) * SW + col] : 0.f;
+                    for (int e = tid; e < SW * 3; e += NT) {              // (position, channel quad): 16-byte stores
+                        const int col = e / 3, q = e - col * 3;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (q < T / 4) {
+                            const float *src = bufA + (4 * q) * SCI + (h + 3) * SW + col;
+                            v = make_float4(src[0], src[SCI], src[2 * SCI], src[3 * SCI]);
+                        }
+                        *reinterpret_cast<float4 *>(d2 + ((h * SW + col) * P + 4 * q)) = v;
                     }
             }
             continue;
