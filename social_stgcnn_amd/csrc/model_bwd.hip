@@ -1217,6 +1217,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         t.tier = a.tier;
         t.Vl = V;
         t.debug_skip = a.debug_skip;
+        t.split_bf16 = getenv("STG_BWD_BF16") ? atoi(getenv("STG_BWD_BF16")) : 0;
         if (!(a.debug_skip & 2)) {
             const int rcw = launch_txp_bwd_wave(t, st);
             if (rcw != STG_OK) return rcw;

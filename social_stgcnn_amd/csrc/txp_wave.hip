@@ -486,6 +486,208 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
         for (int pos = lane; pos < npos; pos += 64) dout[ch * npos + pos] = dcur[pos * P + ch];
 }
 
+// ------------------------------------------------------------------------------------------
+// backward, split-bf16 variant: the input-gradient GEMMs on v_mfma_f32_16x16x16_bf16
+// ------------------------------------------------------------------------------------------
+// Every fp32 operand is split x = hi + lo (two bf16, round-to-nearest-even) and a product is taken as
+// hi*hi + hi*lo + lo*hi with fp32 accumulation: error ~1e-6 of sum|ab| (tools/micro/bf16x3_probe.hip) at 2.6x the
+// rate of the fp32 MFMA.  K = 16 is ONE tap x 12 output channels (+ 4 zero lanes).  The dz plane is position-major:
+// [padded position][12] bf16 for hi, the same for lo behind it -- exactly the bytes of the fp32 plane -- so a lane's
+// B operand (four consecutive channels at one position) is one 8-byte LDS read per part.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned short bf16_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_val(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ void split4(const float (&x)[4], s16x4 &hi, s16x4 &lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned short h = bf16_rne(x[j]);
+        hi[j] = (short)h;
+        lo[j] = (short)bf16_rne(x[j] - bf16_val(h));
+    }
+}
+
+// A operand of tap' for lane (ci = l&15, kq): W[4kq+j][ci][8 - tap'], j = 0..3, split into hi / lo
+template <int CINL>
+__device__ __forceinline__ void load_w_bwd_bf16(const float *__restrict__ W, s16x4 (&whi)[9], s16x4 (&wlo)[9]) {
+    const int lane = threadIdx.x & 63, ci = lane & 15, kq = lane >> 4;
+    const bool live = ci < CINL && kq < 3;
+    const int cc = ci < CINL ? ci : 0, kc = kq < 3 ? kq : 0;
+    float t[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_taps(W + ((4 * kc + j) * CINL + cc) * 9, t[j]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        float x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = live ? t[j][8 - tap] : 0.f;
+        split4(x, whi[tap], wlo[tap]);
+    }
+}
+
+template <int CINL>
+__device__ __forceinline__ void dgrad_layer_bf16(const s16x4 (&whi)[9], const s16x4 (&wlo)[9], const char *hi,
+                                                 const char *lo, float *__restrict__ dcur, const unsigned *ptab, int vi,
+                                                 bool accumulate) {
+    const int kq = (threadIdx.x & 63) >> 4, kc = kq < 3 ? kq : 2;       // lanes kq = 3: finite data x zero weights
+    const int SW = txp_sw(vi), npos = C * vi;
+    const int ntiles = (npos + 15) >> 4;
+    for (int tile0 = 0; tile0 < ntiles; tile0 += 2) {
+        const TileGeom g = tile_geom(tile0, ptab, npos);
+        s16x4 bh[2][9], bl[2][9];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int base = (g.hh[u] * SW + g.ww[u]) * 24 + kc * 8;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int off = base + (kh * SW + kw) * 24;
+                    bh[u][kh * 3 + kw] = *reinterpret_cast<const s16x4 *>(hi + off);
+                    bl[u][kh * 3 + kw] = *reinterpret_cast<const s16x4 *>(lo + off);
+                }
+        }
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wlo[tap], bh[0][tap], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wlo[tap], bh[1][tap], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(whi[tap], bl[0][tap], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(whi[tap], bl[1][tap], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(whi[tap], bh[0][tap], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(whi[tap], bh[1][tap], c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!g.ok[u] || 4 * kq >= CINL) continue;
+            f32x4 *slot = reinterpret_cast<f32x4 *>(dcur + g.pos[u] * P + 4 * kq);
+            f32x4 v = u ? c1 : c0;
+            if (accumulate) v += *slot;
+            *slot = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void txp_bwd_scene_bf16(const TxpBwdArgs &a, int n, float *dzb, float *dcur, unsigned *ptab) {
+    const ModelLayout &L = a.lay;
+    const int V = a.V, lane = threadIdx.x & 63;
+    int vi = a.num_peds ? a.num_peds[n] : V;
+    vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
+    float *slope_row = a.slopes + (int64_t)n * L.n_txp;
+    if (vi == 0) {
+        for (int e = lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;
+        return;
+    }
+    const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi, npad = (C + 2) * SW;
+    const float *Pm = a.params;
+    const float *wsn = a.ws + n * a.ws_stride;
+    const float *dyn = a.dy + (int64_t)n * (C * P) * V;
+    char *hi = reinterpret_cast<char *>(dzb), *lo = hi + npad * 24;          // 2 * npad * 24 B <= P * SC * 4 B
+    wave_zero(dzb, (P * SC) >> 2);
+    build_ptab(ptab, vi, npos);
+    s16x4 whi[9], wlo[9];
+    load_w_bwd_bf16<P>(Pm + L.out_w, whi, wlo);
+    __builtin_amdgcn_wave_barrier();
+    for (int l = L.L; l >= 0; --l) {
+        const bool is_out = l == L.L;
+        float slope_acc = 0.f;
+        if (is_out) {
+            // dz of the output conv is dy: (C*P) rows of V floats, vi valid -> split, position-major plane interior
+            constexpr int U = 4;
+            const int vp = vi <= 1 ? 1 : (vi <= 2 ? 2 : (vi <= 4 ? 4 : (vi <= 8 ? 8 : (vi <= 16 ? 16 : (vi <= 32 ? 32 : 64)))));
+            const int sh = __builtin_ctz(vp), rpi = 64 >> sh;
+            const int sub = lane >> sh, w0 = lane & (vp - 1);
+            for (int wb = 0; wb < vi; wb += 64) {
+                const int w = wb + w0;
+                const bool okw = w < vi;
+                for (int r0 = 0; r0 < C * P; r0 += rpi * U) {
+                    float dv[U];
+                    int bo[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int row = r0 + u * rpi + sub;
+                        const bool ok = okw && row < C * P;
+                        const int rc = ok ? row : 0, ch = rc / C, h = rc - ch * C;
+                        bo[u] = ok ? ((h + 1) * SW + (w + 1)) * 24 + ch * 2 : -1;
+                        dv[u] = ok ? dyn[(int64_t)rc * V + w] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (bo[u] >= 0) {
+                            const unsigned short h16 = bf16_rne(dv[u]);
+                            *reinterpret_cast<unsigned short *>(hi + bo[u]) = h16;
+                            *reinterpret_cast<unsigned short *>(lo + bo[u]) = bf16_rne(dv[u] - bf16_val(h16));
+                        }
+                }
+            }
+        } else {
+            const float *zl = wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V;
+            float *dzo = a.dzg + ((int64_t)n * L.L + l) * dz_slot(V);
+            const float alpha = Pm[L.prelus + l];
+            constexpr int UV = 8;
+            const int nvec = (P * npos) >> 2;
+            const f32x4 *zl4 = reinterpret_cast<const f32x4 *>(zl);
+            for (int v0 = lane; v0 < nvec; v0 += 64 * UV) {
+                f32x4 zv[UV];
+#pragma unroll
+                for (int u = 0; u < UV; ++u) {
+                    const int vv = v0 + 64 * u;
+                    zv[u] = vv < nvec ? zl4[vv] : f32x4{1.f, 1.f, 1.f, 1.f};
+                }
+#pragma unroll
+                for (int u = 0; u < UV; ++u) {
+                    const int vv = v0 + 64 * u;
+                    if (vv < nvec) {
+                        const int p = vv / 3, q = vv - p * 3;
+                        const unsigned hw = ptab[p];
+                        const int h = (int)(hw >> 16), w = (int)(hw & 0xffffu);
+                        const f32x4 dv = reinterpret_cast<const f32x4 *>(dcur)[vv];
+                        f32x4 dzv;
+                        float x[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float z = zv[u][r], d = dv[r];
+                            float dz = d;
+                            if (!(z > 0.f)) {
+                                dz = alpha * d;
+                                slope_acc = fmaf(d, z, slope_acc);
+                            }
+                            dzv[r] = dz;
+                            x[r] = dz;
+                        }
+                        s16x4 h4, l4;
+                        split4(x, h4, l4);
+                        const int bo = ((h + 1) * SW + (w + 1)) * 24 + q * 8;
+                        *reinterpret_cast<s16x4 *>(hi + bo) = h4;
+                        *reinterpret_cast<s16x4 *>(lo + bo) = l4;
+                        reinterpret_cast<f32x4 *>(dzo)[vv] = dzv;
+                    }
+                }
+            }
+            slope_acc = wave_sum(slope_acc);
+            if (lane == 0) slope_row[l] = slope_acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (l == 0) {
+            s16x4 w8h[9], w8l[9];
+            load_w_bwd_bf16<T>(Pm + L.txp_w[0], w8h, w8l);
+            dgrad_layer_bf16<T>(w8h, w8l, hi, lo, dcur, ptab, vi, false);
+        } else {
+            dgrad_layer_bf16<P>(whi, wlo, hi, lo, dcur, ptab, vi, !is_out);
+            if (l > 1) load_w_bwd_bf16<P>(Pm + L.txp_w[l - 1], whi, wlo);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int e = L.L + lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;
+    float *dout = a.da0 + (int64_t)n * (C * T * V);
+    for (int ch = 0; ch < T; ++ch)
+        for (int pos = lane; pos < npos; pos += 64) dout[ch * npos + pos] = dcur[pos * P + ch];
+}
+
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) void txp_bwd_wave_kernel(const TxpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -502,7 +704,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) void txp_bwd_wave_kerne
         const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
-        txp_bwd_scene(a, n, dzb, dcur, ptab);
+        if (a.split_bf16) txp_bwd_scene_bf16(a, n, dzb, dcur, ptab);
+        else txp_bwd_scene(a, n, dzb, dcur, ptab);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -596,7 +799,8 @@ __global__ __launch_bounds__(256, 2) void txp_bwd_wave_mixed_kernel(const TxpBwd
         const int it = walk_item(r, m.worker, m.nworkers, M, a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order[m.begin + it]);
-        txp_bwd_scene(a, n, dzb, dcur, ptab);
+        if (a.split_bf16) txp_bwd_scene_bf16(a, n, dzb, dcur, ptab);
+        else txp_bwd_scene(a, n, dzb, dcur, ptab);
         __builtin_amdgcn_wave_barrier();
     }
 }

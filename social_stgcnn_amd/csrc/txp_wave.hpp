@@ -45,6 +45,7 @@ struct TxpBwdArgs {
     float *da0;            // [N][C*T*V]           gradient w.r.t. the st_gcn block output
     float *slopes;         // [N][n_txp]           per-scene PReLU slope gradients
     int debug_skip;        // timing-only diagnostic (STG_DEBUG_SKIP): 512 dz build, 1024 dgrad tile loops -- wrong results
+    int split_bf16;        // 1: the input-gradient GEMMs run on bf16 MFMAs with hi/lo-split operands (see txp_wave.hip)
 };
 
 // true when the wave-per-scene path serves this model / V (else the workgroup-per-scene kernels run)

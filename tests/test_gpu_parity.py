@@ -701,3 +701,14 @@ def test_every_crowd_size_of_the_wave_path(dev):
         assert not bad, (v, bad)
         worst[v] = max(errs.values())
     assert max(worst.values()) < 1e-3
+
+
+def test_split_bf16_input_gradient_variant(dev, monkeypatch):
+    """STG_BWD_BF16=1 (opt-in): the input-gradient GEMMs on bf16 MFMAs with hi/lo-split operands
+    (hi*hi + hi*lo + lo*hi, fp32 accumulate).  Same checks, same tolerances as the fp32 path: the ragged batch against
+    the oracle, the golden forward/backward cases, and a V sweep subset against the fp64 oracle."""
+    monkeypatch.setenv("STG_BWD_BF16", "1")
+    test_batched_ragged_train_step_vs_oracle(dev)
+    for v in (3, 17, 57):
+        test_train_forward_backward_golden(dev, v)
+    test_ragged_batch_is_order_invariant(dev)
