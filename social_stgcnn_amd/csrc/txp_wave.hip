@@ -688,7 +688,7 @@ __device__ __forceinline__ void txp_bwd_scene_bf16(const TxpBwdArgs &a, int n, f
         for (int pos = lane; pos < npos; pos += 64) dout[ch * npos + pos] = dcur[pos * P + ch];
 }
 
-template <int WPB>
+template <int WPB, bool BF16>
 __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) void txp_bwd_wave_kernel(const TxpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Vl = a.Vl, wave = threadIdx.x >> 6;
@@ -704,8 +704,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) void txp_bwd_wave_kerne
         const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
-        if (a.split_bf16) txp_bwd_scene_bf16(a, n, dzb, dcur, ptab);
-        else txp_bwd_scene(a, n, dzb, dcur, ptab);
+        if (BF16) txp_bwd_scene_bf16(a, n, dzb, dcur, ptab);      // (separate instantiations: the variants
+        else txp_bwd_scene(a, n, dzb, dcur, ptab);               //  do not share a register budget)
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -786,6 +786,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(256, 2) void txp_bwd_wave_mixed_kernel(const TxpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const MixSlot m = mix_assign(a.tier, a.mix, a.N, a.V);
@@ -799,8 +800,8 @@ __global__ __launch_bounds__(256, 2) void txp_bwd_wave_mixed_kernel(const TxpBwd
         const int it = walk_item(r, m.worker, m.nworkers, M, a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order[m.begin + it]);
-        if (a.split_bf16) txp_bwd_scene_bf16(a, n, dzb, dcur, ptab);
-        else txp_bwd_scene(a, n, dzb, dcur, ptab);
+        if (BF16) txp_bwd_scene_bf16(a, n, dzb, dcur, ptab);      // (separate instantiations: the variants
+        else txp_bwd_scene(a, n, dzb, dcur, ptab);               //  do not share a register budget)
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -903,10 +904,14 @@ int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {
     TxpBwdArgs a = a0;
     if (mix_geom(bwd_per_wave_floats, a.V, a.tier.order && a.tier.key_start, &a.mix)) {
         const size_t lds = (size_t)a.mix.block_floats * sizeof(float);
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_bwd_wave_mixed_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const void *fn = a.split_bf16 ? reinterpret_cast<const void *>(&txp_bwd_wave_mixed_kernel<true>)
+                                      : reinterpret_cast<const void *>(&txp_bwd_wave_mixed_kernel<false>);
+        hipError_t e_ = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e_ != hipSuccess) return hip_fail(e_, "txp_bwd_wave_mixed: hipFuncSetAttribute");
-        hipLaunchKernelGGL(txp_bwd_wave_mixed_kernel, dim3(mix_grid(lds, a.N)), dim3(256), lds, st, a);
+        if (a.split_bf16)
+            hipLaunchKernelGGL(txp_bwd_wave_mixed_kernel<true>, dim3(mix_grid(lds, a.N)), dim3(256), lds, st, a);
+        else
+            hipLaunchKernelGGL(txp_bwd_wave_mixed_kernel<false>, dim3(mix_grid(lds, a.N)), dim3(256), lds, st, a);
         STG_LAUNCH_CHECK("txp_bwd_wave_mixed");
         return STG_OK;
     }
@@ -914,15 +919,20 @@ int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {
     const int wpb = wave_wpb(per_wave);
     const size_t lds = per_wave * wpb;
     const dim3 grid(wave_grid(lds, wpb, a.N));
-#define STG_L(W)                                                                                              \
+#define STG_L2(W, B)                                                                                          \
     do {                                                                                                      \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_bwd_wave_kernel<W>),          \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_bwd_wave_kernel<W, B>),       \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
         if (e_ != hipSuccess) return hip_fail(e_, "txp_bwd_wave: hipFuncSetAttribute");                       \
-        hipLaunchKernelGGL(txp_bwd_wave_kernel<W>, grid, dim3(W * 64), lds, st, a);                           \
+        hipLaunchKernelGGL((txp_bwd_wave_kernel<W, B>), grid, dim3(W * 64), lds, st, a);                      \
+    } while (0)
+#define STG_L(W)                                                                                              \
+    do {                                                                                                      \
+        if (a.split_bf16) STG_L2(W, true); else STG_L2(W, false);                                             \
     } while (0)
     if (wpb == 8) STG_L(8); else if (wpb == 4) STG_L(4); else if (wpb == 2) STG_L(2); else STG_L(1);
 #undef STG_L
+#undef STG_L2
     STG_LAUNCH_CHECK("txp_bwd_wave");
     return STG_OK;
 }
