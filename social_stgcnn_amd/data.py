@@ -63,9 +63,12 @@ class SceneWindows:
 
 
 def load_windows(data_dir, obs_len=8, pred_len=12, skip=1, threshold=0.002, min_ped=1,
-                 delim="\t", with_non_linear=True):
+                 delim="\t", with_non_linear=True, files=None):
+    """`files`: file names inside data_dir in the order to ingest them (default: sorted).  The reference
+    walks os.listdir order (utils.py:116-117), which decides the order of the windows of a multi-file split."""
     seq_len = obs_len + pred_len
-    files = sorted(os.path.join(data_dir, p) for p in os.listdir(data_dir))
+    names = sorted(os.listdir(data_dir)) if files is None else [str(f) for f in files]
+    files = [os.path.join(data_dir, p) for p in names]
     seqs, rels, masks, nonlin, counts = [], [], [], [], []
     max_peds = 0
     for path in files:

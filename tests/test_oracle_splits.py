@@ -1,0 +1,98 @@
+"""CPU: the oracle and the host ingest against the five-split / eth-train fixtures the reference produced
+(tests/golden/make_golden_splits.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from oracle import stgcnn_oracle as O
+from social_stgcnn_amd import data
+
+SPLITS = ("eth", "hotel", "univ", "zara1", "zara2")
+# windows / pedestrians / largest crowd per test split and for eth/train, measured with the reference's
+# TrajectoryDataset
+COUNTS = {"eth_test": (70, 181, 5), "hotel_test": (301, 1053, 8), "univ_test": (947, 24334, 57),
+          "zara1_test": (602, 2253, 14), "zara2_test": (921, 5833, 14), "eth_train": (2785, 29809, 57)}
+
+
+def _state(npz, prefix=""):
+    return {k[len(prefix):]: torch.from_numpy(np.array(npz[k])) for k in npz.files if k.startswith(prefix)}
+
+
+def _windows(name, files=None):
+    return data.load_windows(os.path.join(GOLDEN, "data", name), 8, 12, 1, with_non_linear=False, files=files)
+
+
+@pytest.mark.parametrize("name", sorted(COUNTS))
+def test_ingest_window_counts(name):
+    w = _windows(name)
+    assert (len(w), int(w.num_peds.sum()), int(w.num_peds.max())) == COUNTS[name]
+
+
+def test_eth_train_windows_follow_the_reference_file_order():
+    g = load_golden("eth_train_epoch.npz")
+    w = _windows("eth_train", [str(f) for f in g["listdir_order"]])
+    assert np.array_equal(w.num_peds, g["num_peds"])
+
+
+@pytest.mark.parametrize("name", SPLITS)
+def test_oracle_vpred_on_every_split(name):
+    """oracle forward (eval mode, the split's shipped weights) on every k-th test window == the reference's V_pred."""
+    g = load_golden("eval_splits.npz")
+    w = _windows(name + "_test")
+    assert np.array_equal(w.num_peds, g[name + "/num_peds"])
+    state = _state(load_golden("weights_%s.npz" % name))
+    every, ref = int(g[name + "/vpred_every"]), g[name + "/vpred_cat"]
+    idx = list(range(0, len(w), every))
+    if name == "univ":
+        idx = idx[::4]                       # CPU time: 15 of the 60 fixture windows (V up to 57)
+    col = 0
+    cols = {}
+    for i in range(0, len(w), every):
+        cols[i] = col
+        col += int(w.num_peds[i])
+    worst = 0.0
+    with torch.no_grad():
+        for i in idx:
+            s, e = w.seq_start_end[i]
+            nodes, lap = O.seq_to_graph_np(w.seq_rel[s:e, :, :8].astype(np.float32))
+            y = O.social_stgcnn_forward(state, torch.from_numpy(nodes).unsqueeze(0).permute(0, 3, 1, 2),
+                                        torch.from_numpy(lap), False)
+            vp = y[0].permute(1, 2, 0).numpy()                      # (P,V,5)
+            worst = max(worst, float(np.abs(vp - ref[:, cols[i]:cols[i] + (e - s)]).max()))
+    assert worst < 2e-5, worst
+
+
+def test_oracle_reproduces_the_reference_eth_train_epoch():
+    """BASELINE configs[1] data: the reference's train() over the 2,785 eth/train windows (dataset order, batch_size
+    512, six optimizer steps) through the oracle's group step: epoch loss and every weight / running statistic."""
+    g = load_golden("eth_train_epoch.npz")
+    w = _windows("eth_train", [str(f) for f in g["listdir_order"]])
+    state = _state(g, "before/")
+    keys = [k for k in state if "running" not in k and "num_batches" not in k]
+    bs = int(g["batch_size"])
+    bounds = O.group_boundaries(len(w), bs)
+    assert bounds == [511, 1023, 1535, 2047, 2559, 2784]
+    torch.set_num_threads(1)
+    scenes = []
+    for i in range(len(w)):
+        s, e = w.seq_start_end[i]
+        rel = w.seq_rel[s:e].astype(np.float32)
+        nodes, lap = O.seq_to_graph_np(rel[:, :, :8])
+        tgt, _ = O.seq_to_graph_np(rel[:, :, 8:])
+        scenes.append((torch.from_numpy(nodes).unsqueeze(0).permute(0, 3, 1, 2), torch.from_numpy(lap),
+                       torch.from_numpy(tgt)))
+    total, lo = 0.0, 0
+    for b in bounds:
+        loss, _ = O.train_group(state, scenes[lo:b + 1], bs, float(g["lr"]), keys)
+        total += loss
+        lo = b + 1
+    assert abs(total / len(w) - float(g["epoch_loss"])) < 1e-7
+    for k in state:
+        ref = g["after/" + k]
+        if "num_batches" in k:
+            assert int(state[k]) == int(ref)
+        else:
+            np.testing.assert_allclose(state[k].detach().numpy(), ref, rtol=2e-5, atol=2e-6, err_msg=k)
