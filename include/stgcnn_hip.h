@@ -9,9 +9,12 @@
  * Conventions
  *  - plain pointers (DEVICE memory unless stated) and sizes; fp32 data, int32 counts.
  *  - every function returns 0 on success, a negative STG_E* code for invalid arguments, or a
- *    positive hipError_t; it never aborts, allocates nothing, does not synchronise the host
- *    and keeps no mutable global state (re-entrant across streams).  Work is enqueued on
- *    `stream` (a hipStream_t passed as void*; NULL = the default stream).
+ *    positive hipError_t; it never aborts, allocates nothing, does not synchronise the host,
+ *    reads no environment variable and keeps no mutable global state (re-entrant across
+ *    streams; the only per-thread state is the text behind stg_last_error()).  Every choice a
+ *    caller can make -- kernel path, waves per scene, storage type -- is an explicit argument
+ *    (stg_model_desc.flags / .wg_waves).  Work is enqueued on `stream` (a hipStream_t passed as
+ *    void*; NULL = the default stream).
  *  - a batch holds N scene-windows padded to V pedestrian slots; `num_peds` (int32[N], may be
  *    NULL = all V valid) gives the real count V_i of each scene.  Slots >= V_i are ignored on
  *    input and written as zeros on output.
@@ -33,7 +36,7 @@ extern "C" {
 #define STG_EUNSUPPORTED (-2) /* configuration outside what the kernels are built for      */
 #define STG_ELDS (-3)        /* scene too large for the 160 KiB LDS of one CU             */
 
-#define STG_ABI_VERSION 4
+#define STG_ABI_VERSION 5
 #define STG_MAX_BLOCKS 4     /* st_gcn blocks in one fused model                          */
 
 int stg_abi_version(void);
@@ -107,7 +110,13 @@ typedef struct {
                            /* reference's N=1 training loop, train.py:36-77)                    */
     float bn_eps;          /* 1e-5                                                              */
     float bn_momentum;     /* 0.1                                                               */
+    int32_t flags;         /* STG_OPT_* bit set, 0 = defaults.  Part of the descriptor because it decides  */
+                           /* the workspace / scratch layouts the size queries report                      */
+    int32_t wg_waves;      /* 0 = auto; 1, 2, 4 or 8: waves per scene of the workgroup-per-scene kernels   */
 } stg_model_desc;
+
+#define STG_OPT_WG_PATH 1     /* run the workgroup-per-scene kernels even where the wave-per-scene path fits */
+#define STG_OPT_SPLIT_BF16 2  /* TXP input-gradient GEMMs on bf16 MFMAs with hi/lo-split operands (fp32 in/out) */
 
 int64_t stg_model_param_count(const stg_model_desc *d);
 int64_t stg_model_buffer_count(const stg_model_desc *d);
@@ -130,7 +139,10 @@ int64_t stg_model_bwd_scratch_floats(const stg_model_desc *d, int N, int V);
 int stg_model_fwd(const stg_model_desc *d, const float *params, const float *buffers,
                   const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv,
                   const float *adj, int64_t a_sn, const int32_t *num_peds, int N, int V,
-                  float *y, float *ws, float *stats, float *scratch, void *stream);
+                  float *y, float *ws, float *stats, float *scratch, void **events, int n_events, void *stream);
+/* events (may be NULL): n_events hipEvent_t handles for per-kernel device timing -- the entry point records
+ * events[0] on `stream` before its first kernel and events[k] after its k-th kernel, as far as n_events reaches
+ * (stg_model_fwd / stg_model_bwd kernel order: see DESIGN.md section 5).                                      */
 /* dy like y.  grad_params (param_count) is OVERWRITTEN with the gradient summed over the batch;
  * dx (N,c_in,t_obs,V) may be NULL.  scratch: stg_model_bwd_scratch_floats floats, 16-byte aligned
  * (ws must be 16-byte aligned too).                                                               */
@@ -138,7 +150,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
                   const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv,
                   const float *adj, int64_t a_sn, const int32_t *num_peds, int N, int V,
                   const float *dy, const float *ws, float *scratch, float *grad_params, float *dx,
-                  void *stream);
+                  void **events, int n_events, void *stream);
 /* Sequential-fold update of the BatchNorm running statistics with the per-scene statistics of a
  * batch, exactly as N successive reference forwards would (momentum update per scene,
  * model.py:114,123,140; SURVEY 7 'BatchNorm semantics').  Scenes with num_peds[n] == 0 are skipped.

@@ -12,8 +12,12 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libstgcnn_hip.so")
-ABI_VERSION = 4
+# STG_USE_DIAG_LIB=1 (tools/ only) loads the diagnostic build `make -C csrc DIAG=1` produces; the product
+# library reads no environment variable itself
+DIAG = os.environ.get("STG_USE_DIAG_LIB", "0") not in ("", "0")
+LIB_PATH = os.path.join(CSRC, "libstgcnn_hip_diag.so" if DIAG else "libstgcnn_hip.so")
+ABI_VERSION = 5
+OPT_WG_PATH, OPT_SPLIT_BF16 = 1, 2
 
 c_f = ctypes.c_void_p          # device pointers travel as void*
 c_i = ctypes.c_int
@@ -25,7 +29,8 @@ class ModelDesc(ctypes.Structure):
     _fields_ = [("n_stgcnn", ctypes.c_int32), ("n_txpcnn", ctypes.c_int32), ("c_in", ctypes.c_int32),
                 ("c_out", ctypes.c_int32), ("t_obs", ctypes.c_int32), ("t_pred", ctypes.c_int32),
                 ("kt", ctypes.c_int32), ("residual0", ctypes.c_int32), ("use_mdn", ctypes.c_int32),
-                ("bn_mode", ctypes.c_int32), ("bn_eps", ctypes.c_float), ("bn_momentum", ctypes.c_float)]
+                ("bn_mode", ctypes.c_int32), ("bn_eps", ctypes.c_float), ("bn_momentum", ctypes.c_float),
+                ("flags", ctypes.c_int32), ("wg_waves", ctypes.c_int32)]
 
 
 _SIGNATURES = {
@@ -44,9 +49,9 @@ _SIGNATURES = {
     "stg_model_fwd_scratch_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i, c_i]),
     "stg_model_bwd_scratch_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i, c_i]),
     "stg_model_fwd": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_f, c_l, c_l, c_l, c_l, c_f, c_l, c_f, c_i, c_i,
-                            c_f, c_f, c_f, c_f, c_f]),
+                            c_f, c_f, c_f, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f]),
     "stg_model_bwd": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_f, c_l, c_l, c_l, c_l, c_f, c_l, c_f, c_i, c_i,
-                            c_f, c_f, c_f, c_f, c_f, c_f]),
+                            c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f]),
     "stg_bn_fold": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_i, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f]),
     "stg_nll_fwd": (c_i, [c_f, c_l, c_l, c_l, c_l, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f]),
     "stg_nll_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
@@ -64,7 +69,7 @@ _lib = None
 
 def build(verbose=False):
     """Compile libstgcnn_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC, "-j8"]
+    cmd = ["make", "-C", CSRC, "-j8"] + (["DIAG=1"] if DIAG else [])
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)
@@ -91,6 +96,51 @@ def lib():
             raise RuntimeError("libstgcnn_hip.so ABI %d != binding ABI %d" % (h.stg_abi_version(), ABI_VERSION))
         _lib = h
     return _lib
+
+
+class HipEvents:
+    """hipEvent_t handles for the per-kernel device timing the fused entry points offer (`events` argument of
+    stg_model_fwd / stg_model_bwd): created through the HIP runtime torch already loaded, recorded by the library on
+    the launch stream, read back here."""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            h = ctypes.CDLL("libamdhip64.so")
+            h.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+            h.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+            h.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+            h.hipEventDestroy.argtypes = [ctypes.c_void_p]
+            cls._hip = h
+        return cls._hip
+
+    def __init__(self, n):
+        self.n = n
+        self.arr = (ctypes.c_void_p * n)()
+        for i in range(n):
+            ev = ctypes.c_void_p()
+            if self.hip().hipEventCreate(ctypes.byref(ev)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+            self.arr[i] = ev
+
+    def intervals_ms(self):
+        """[t(events[k]) - t(events[k-1]) for k = 1..n-1] after the stream has drained."""
+        out = []
+        self.hip().hipEventSynchronize(self.arr[self.n - 1])
+        for k in range(1, self.n):
+            ms = ctypes.c_float()
+            if self.hip().hipEventElapsedTime(ctypes.byref(ms), self.arr[k - 1], self.arr[k]) != 0:
+                raise RuntimeError("hipEventElapsedTime failed")
+            out.append(ms.value)
+        return out
+
+    def __del__(self):
+        try:
+            for i in range(self.n):
+                self.hip().hipEventDestroy(self.arr[i])
+        except Exception:
+            pass
 
 
 def check(rc, what):

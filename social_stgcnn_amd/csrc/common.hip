@@ -1,5 +1,6 @@
 // Error reporting + small utility kernels (SGD step, MFMA self-test).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace stg {
 
@@ -14,6 +15,13 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     return code;
 }
+
+#ifdef STG_DIAG
+int diag_env(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#endif
 
 int hip_fail(hipError_t e, const char *what) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));

@@ -27,6 +27,27 @@ int hip_fail(hipError_t e, const char *what);
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// The product library reads NO environment variable.  A diagnostic build (make DIAG=1 -> -DSTG_DIAG,
+// libstgcnn_hip_diag.so, used by tools/ only) can override tuning constants and skip kernel phases for timing.
+#ifdef STG_DIAG
+int diag_env(const char *name, int dflt);
+#define STG_SKIP(args, bit) (((args).debug_skip & (bit)) != 0)
+#else
+static inline int diag_env(const char *, int dflt) { return dflt; }
+#define STG_SKIP(args, bit) false
+#endif
+
+// per-kernel device timing requested by the caller (stg_model_fwd / stg_model_bwd `events`)
+struct EventList {
+    void **ev;
+    int n, next;
+    hipStream_t st;
+    void mark() {
+        if (ev && next < n) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[next]), st);
+        ++next;
+    }
+};
+
 constexpr int kWave = 64;           // gfx950 wavefront
 constexpr int kLdsBytes = 160 * 1024;
 constexpr int kNumCU = 256;

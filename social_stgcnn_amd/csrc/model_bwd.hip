@@ -665,7 +665,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
                     if (tid == 0) gsm[L.n_blk_params + l] += tot[0];
                 }
                 const int w_off = is_out ? L.out_w : L.txp_w[l];
-                if (!(a.debug_skip & 2)) {
+                if (!STG_SKIP(a, 2)) {
                     if (l == 0)
                         txp_dgrad<Cfg::T, WAVES>(Pm + w_off, dzb, dcur, vi, false);
                     else
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
         // ---- st_gcn blocks, last to first ------------------------------------------------------
         // lean image: db1 reuses the du plane (dcur), which is dead once dh2 / dr have been formed
         float *H1 = dzb, *DH2 = dzb + C * (T + 2) * Vl, *DB1 = lean ? dcur : DH2 + C * (T + 2) * Vl;
-        for (int j = L.n_blocks - 1; j >= 0 && !(a.debug_skip & 4); --j) {
+        for (int j = L.n_blocks - 1; j >= 0 && !STG_SKIP(a, 4); --j) {
             const float *xin = j > 0 ? wsn + L.ws_hdr_floats + (int64_t)L.blk[j - 1].ws_s * V : nullptr;
             if (lean && a.stage) {       // x[n] was staged behind the saved arrays
                 const int n_ax = (L.blk[0].cin * T * vi + 3) & ~3, n_cs = (T * vi + 3) & ~3, n_g = (C * T * vi + 3) & ~3;
@@ -823,7 +823,7 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
         if (vfull == 0 || chunk >= nc) continue;
         const int wc = (vfull + nc - 1) / nc, w0 = chunk * wc;         // equal chunks
         const int vi = (vfull - w0) < wc ? (vfull - w0) : wc;          // from here on: the chunk IS the scene
-        if (!(a.debug_skip & 64)) wgrad_stage<CINL>(a, layer, n, vfull, w0, vi, cur, cur + pslot);
+        if (!STG_SKIP(a, 64)) wgrad_stage<CINL>(a, layer, n, vfull, w0, vi, cur, cur + pslot);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // image of scene n complete
         __builtin_amdgcn_wave_barrier();
         const float *plane = cur, *dzs = cur + pslot;
@@ -835,8 +835,8 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float
             boff[tl] = ((tap / 3 - 1) * SW + (tap % 3 - 1)) * P + ci;
         }
         // K loop over the scene's positions, 4 per MFMA; this lane walks p = kq, kq+4, ...
-        const int nsteps = (a.debug_skip & 128) ? 0 : (npos + 3) >> 2;
-        const int nfull = vi >= 4 ? ((a.debug_skip & 128) ? 0 : (npos >> 2)) : 0;   // steps without a K tail
+        const int nsteps = STG_SKIP(a, 128) ? 0 : (npos + 3) >> 2;
+        const int nfull = vi >= 4 ? (STG_SKIP(a, 128) ? 0 : (npos >> 2)) : 0;   // steps without a K tail
         int w = kq;                                  // vi >= 4 on the fast path: h = 0
         int pos_off = (SW + 1 + kq) * P;             // ((h+1)*SW + (w+1)) * P
         int a_idx = kq * P + co_a;                   // dz is position-major [pos][P]
@@ -990,12 +990,9 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceArgs a) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static int env_waves(const char *name, int dflt) {
-    if (const char *e = getenv(name)) {
-        const int w = atoi(e);
-        if (w == 1 || w == 2 || w == 4 || w == 8) return w;
-    }
-    return dflt;
+static int env_waves(const char *name, int dflt) {     // (diagnostic builds only; the product returns dflt)
+    const int w = diag_env(name, dflt);
+    return (w == 1 || w == 2 || w == 4 || w == 8) ? w : dflt;
 }
 
 static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves, bool lean = false, bool stage = true) {
@@ -1012,7 +1009,7 @@ static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves, bool lean = 
 
 // measured (profiles/): the st_gcn backward is fastest with ONE wave per scene up to V ~ 40 (no cross-wave
 // barriers in its ~15 block reductions), more waves only when a scene's rows no longer fit one wave's registers
-static int bwd_waves(int V) { return env_waves("STG_BWD_WAVES", V <= 40 ? 1 : (V <= 80 ? 4 : 8)); }
+static int bwd_waves(const ModelLayout &L, int V) { return L.wg_waves ? L.wg_waves : (V <= 40 ? 1 : (V <= 80 ? 4 : 8)); }
 
 // lean image: stage the block's saved arrays in LDS (one DMA burst instead of an HBM round trip per pass) unless
 // that costs residency -- at V = 32 the staged image admits 4 workgroups per CU, the plain one 8 = one scene per
@@ -1035,14 +1032,11 @@ static int bwd_grid_w(const ModelLayout &L, int N, int V, int waves, bool lean) 
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
     int grid = kNumCU * per_cu;
-    if (const char *e = getenv("STG_BWD_GRID")) {
-        const int g = atoi(e);
-        if (g > 0) grid = g;
-    }
+    if (const int g = diag_env("STG_BWD_GRID", 0)) grid = g > 0 ? g : grid;
     return grid < N ? grid : N;
 }
 static int bwd_grid(const ModelLayout &L, int N, int V, bool lean = false) {
-    return bwd_grid_w(L, N, V, bwd_waves(V), lean);
+    return bwd_grid_w(L, N, V, bwd_waves(L, V), lean);
 }
 // ragged batches padded beyond kBwdTierV: the scenes up to kBwdTierV pedestrians (most of a real batch) run in a
 // second launch with ONE wave per scene and the LDS image of V = kBwdTierV; slab rows of both launches are stacked
@@ -1069,10 +1063,7 @@ static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
     if (per_cu * waves > 8) per_cu = 8 / waves > 0 ? 8 / waves : 1;
     if (per_cu < 1) per_cu = 1;
     int total = kNumCU * per_cu;                       // resident workgroups on the chip
-    if (const char *e = getenv("STG_WGRAD_GRID")) {
-        const int v = atoi(e);
-        if (v > 0) total = v;
-    }
+    if (const int v = diag_env("STG_WGRAD_GRID", 0)) total = v > 0 ? v : total;
     const int nl = L.L + 1;
     if (total < nl) total = nl;
     const int need = (N * wgrad_chunks(V) + waves - 1) / waves;   // never more workgroups per layer than items need
@@ -1141,7 +1132,7 @@ int64_t stg_model_bwd_scratch_floats(const stg_model_desc *d, int N, int V) {
 int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
                   int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj, int64_t a_sn, const int32_t *num_peds,
                   int N, int V, const float *dy, const float *ws, float *scratch, float *grad_params, float *dx,
-                  void *stream) {
+                  void **events, int n_events, void *stream) {
     using namespace stg;
     BwdArgs a{};
     const int rc = make_layout(d, &a.lay);
@@ -1154,13 +1145,15 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     STG_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0,
                 STG_EINVAL, "stg_model_bwd: ws / scratch must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
+    EventList evl{events, events ? n_events : 0, 0, st};
+    evl.mark();
     if (N == 0) {
         hipError_t e = hipMemsetAsync(grad_params, 0, sizeof(float) * L.n_params, st);
         if (e != hipSuccess) return hip_fail(e, "stg_model_bwd: memset");
         return STG_OK;
     }
     const bool lean = txp_wave_fits(L, V) && dx == nullptr && L.n_blocks == 1;
-    const int waves = bwd_waves(V);
+    const int waves = bwd_waves(L, V);
     const bool stage = lean && bwd_stage(L, V, waves);
     const size_t lds = bwd_lds_bytes(L, V, waves, lean, stage);
     STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_bwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
@@ -1206,10 +1199,9 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     // ragged batch: sorted scene list at the tail of the scratch buffer (see bwd_scratch_floats)
     int32_t *order = reinterpret_cast<int32_t *>(scratch + bwd_scratch_floats(L, N, V) - order_floats(N, V));
     const bool sorted = launch_scene_order(num_peds, N, V, order, order + N, st);
-    int serp = 1;
-    if (const char *e = getenv("STG_WALK")) serp = atoi(e);
+    const int serp = diag_env("STG_WALK", 1);
     a.tier = SceneTier{sorted ? order : nullptr, sorted ? order + N : nullptr, -1, V, serp};
-    if (const char *e = getenv("STG_DEBUG_SKIP")) a.debug_skip = atoi(e);
+    a.debug_skip = diag_env("STG_DEBUG_SKIP", 0);
     if (wave_path) {
         TxpBwdArgs t{};
         t.lay = L; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V; t.dy = dy; t.ws = ws;
@@ -1217,11 +1209,12 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         t.tier = a.tier;
         t.Vl = V;
         t.debug_skip = a.debug_skip;
-        t.split_bf16 = getenv("STG_BWD_BF16") ? atoi(getenv("STG_BWD_BF16")) : 0;
-        if (!(a.debug_skip & 2)) {
+        t.split_bf16 = (L.flags & STG_OPT_SPLIT_BF16) ? 1 : 0;
+        if (!STG_SKIP(a, 2)) {
             const int rcw = launch_txp_bwd_wave(t, st);
             if (rcw != STG_OK) return rcw;
         }
+        evl.mark();
         a.da0 = da0;
     }
 #define STG_LAUNCH_BWD(W)                                                                                    \
@@ -1268,6 +1261,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     }
 #undef STG_LAUNCH_BWD
     STG_LAUNCH_CHECK("stg_model_bwd: K1");
+    evl.mark();
 
     ReduceArgs r{};
     r.slabs = scratch;
@@ -1276,14 +1270,14 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     r.seg[r.n_seg++] = ReduceSeg{0, L.n_blk_params, slab_rows, n_small, 0};
     if (L.n_txp > 0) {
         if (wave_path)
-            r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, (a.debug_skip & 2) ? 0 : N, L.n_txp, (int64_t)(slopes - scratch)};
+            r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, STG_SKIP(a, 2) ? 0 : N, L.n_txp, (int64_t)(slopes - scratch)};
         else
             r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, slab_rows, n_small, (int64_t)L.n_blk_params};
         WgradArgs w{};
         w.lay = L; w.num_peds = num_peds; w.order = a.tier.order; w.serpentine = a.tier.serpentine; w.N = N; w.V = V; w.dy = dy; w.ws = ws; w.dzg = dzg;
         w.ws_stride = a.ws_stride; w.slab2 = slab2; w.rows = wg.rows; w.debug_skip = a.debug_skip;
         for (int l = 0; l <= L.L + 1; ++l) w.wg_begin[l] = wg.wg_begin[l];
-        if (!(a.debug_skip & 1)) {
+        if (!STG_SKIP(a, 1)) {
             const dim3 g2(wg.grid);
 #define STG_LAUNCH_WG(W)                                                                                     \
     do {                                                                                                     \
@@ -1301,16 +1295,18 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
 #undef STG_LAUNCH_WG
             STG_LAUNCH_CHECK("stg_model_bwd: K2");
         }
+        evl.mark();
         const int64_t s2 = slab2 - scratch;
         for (int l = 0; l <= L.L; ++l) {
             const int p0 = l == L.L ? L.out_w : L.txp_w[l];
             // (only the rows the layer's workgroups wrote: no memset of the slab needed)
-            r.seg[r.n_seg++] = ReduceSeg{p0, wgrad_row_len(l), (a.debug_skip & 1) ? 0 : wg.wg_begin[l + 1] - wg.wg_begin[l],
+            r.seg[r.n_seg++] = ReduceSeg{p0, wgrad_row_len(l), STG_SKIP(a, 1) ? 0 : wg.wg_begin[l + 1] - wg.wg_begin[l],
                                          wgrad_row_len(l), s2 + wgrad_slab_base(l, wg.rows)};
         }
     }
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((L.n_params + 7) / 8), dim3(256), 0, st, r);
     STG_LAUNCH_CHECK("stg_model_bwd: reduce_slabs");
+    evl.mark();
     return STG_OK;
 }
 

@@ -39,6 +39,7 @@ struct ModelLayout {
     int32_t n_blk_params;
     int32_t use_mdn, bn_mode;
     float eps, momentum;
+    int32_t flags, wg_waves;        // stg_model_desc.flags / .wg_waves
 };
 
 // Fills `lay` from the public descriptor; returns STG_OK or an error code (message in last_error).

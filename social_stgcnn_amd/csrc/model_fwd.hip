@@ -453,7 +453,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
             }
         }
         __syncthreads();
-        for (int j = 0; j < L.n_blocks && !(a.debug_skip & 32); ++j) {
+        for (int j = 0; j < L.n_blocks && !STG_SKIP(a, 32); ++j) {
             const bool last = j == L.n_blocks - 1;
             float *yb = (last && L.n_txp == 0) ? yn : nullptr;
             if (L.blk[j].cin == Cfg::CIN0)
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_fwd_kernel(const FwdArgs a, 
                                                last && L.n_txp > 0, a.a0g ? bufA + 2 * SW : bufA, yb, !last);
             float *tmp = X; X = H; H = tmp;      // block output becomes the next block's input
         }
-        if (L.n_txp == 0 || (a.debug_skip & 16)) continue;
+        if (L.n_txp == 0 || STG_SKIP(a, 16)) continue;
         if (a.a0g) {
             // hand the zero-bordered channel-major a_0 plane to txp_fwd_wave_kernel (linear 16-byte copy) and,
             // in training, save it position-major for the weight-gradient GEMM
@@ -539,7 +539,7 @@ extern "C" int64_t stg_model_fwd_scratch_floats(const stg_model_desc *d, int N, 
     const int rc = stg::make_layout(d, &l);
     if (rc != STG_OK) return rc;
     if (N < 0 || V <= 0) return stg::fail(STG_EINVAL, "stg_model_fwd_scratch_floats: N=%d V=%d", N, V);
-    const bool stamps = getenv("STG_STAMPS") != nullptr;
+    const bool stamps = stg::diag_env("STG_STAMPS", 0) != 0;
     return stg::txp_wave_fits(l, V)
                ? (((int64_t)N * stg::a0_slot(V) + 3) & ~(int64_t)3) + 4 + stg::order_floats(N, V) + (stamps ? (int64_t)N * 32 : 0)
                : 0;
@@ -548,7 +548,7 @@ extern "C" int64_t stg_model_fwd_scratch_floats(const stg_model_desc *d, int N, 
 extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const float *buffers, const float *x,
                              int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj,
                              int64_t a_sn, const int32_t *num_peds, int N, int V, float *y, float *ws,
-                             float *stats, float *scratch, void *stream) {
+                             float *stats, float *scratch, void **events, int n_events, void *stream) {
     using namespace stg;
     FwdArgs a{};
     const int rc = make_layout(d, &a.lay);
@@ -566,17 +566,16 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     STG_REQUIRE(!ws || (reinterpret_cast<uintptr_t>(ws) & 15) == 0, STG_EINVAL, "stg_model_fwd: ws must be 16-byte aligned");
     a.a0g = wave_path ? scratch : nullptr;
     hipStream_t st = as_stream(stream);
+    EventList evl{events, events ? n_events : 0, 0, st};
+    evl.mark();
     if (wave_path) {     // ragged batch: sorted scene list behind the a_0 planes
         int32_t *order = reinterpret_cast<int32_t *>(scratch + (((int64_t)N * a0_slot(V) + 3) & ~(int64_t)3) + 4);
         a.order = launch_scene_order(num_peds, N, V, order, order + N, st) ? order : nullptr;
     }
-    if (const char *e = getenv("STG_DEBUG_SKIP")) a.debug_skip = atoi(e);
+    a.debug_skip = diag_env("STG_DEBUG_SKIP", 0);
     int waves = V <= 12 ? 1 : (V <= 40 ? 2 : (V <= 80 ? 4 : 8));
     if (wave_path) waves = V <= 4 ? 1 : 2;     // blocks only (measured at V=32: 2 waves 74 us, 4: 79, 1: 96, 8: 172)
-    if (const char *e = getenv("STG_FWD_WAVES")) {
-        const int w = atoi(e);
-        if (w == 1 || w == 2 || w == 4 || w == 8) waves = w;
-    }
+    if (a.lay.wg_waves) waves = a.lay.wg_waves;
     const size_t lds = fwd_lds_bytes(V, waves, wave_path, a.lay.blk[0].cin);
     STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_fwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
                 kLdsBytes);
@@ -596,18 +595,20 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     }
 #undef STG_LAUNCH_FWD
     STG_LAUNCH_CHECK("stg_model_fwd");
-    if (wave_path && !(a.debug_skip & 16)) {
+    evl.mark();
+    if (wave_path && !STG_SKIP(a, 16)) {
         TxpFwdArgs t{};
         t.lay = a.lay; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V;
         t.a0g = scratch; t.y = y; t.ws = ws; t.ws_stride = a.ws_stride;
-        t.stamps = getenv("STG_STAMPS") ? reinterpret_cast<unsigned long long *>(scratch + (((int64_t)N * a0_slot(V) + 3) & ~(int64_t)3) + 4 + order_floats(N, V)) : nullptr;
-        int serp = 1;
-        if (const char *e = getenv("STG_WALK")) serp = atoi(e);
+        t.stamps = diag_env("STG_STAMPS", 0) ? reinterpret_cast<unsigned long long *>(scratch + (((int64_t)N * a0_slot(V) + 3) & ~(int64_t)3) + 4 + order_floats(N, V)) : nullptr;
+        const int serp = diag_env("STG_WALK", 1);
         // one launch for the whole (sorted) batch: V-tiers in separate launches were measured slower -- the few
         // large scenes of a real batch take one wave tens of microseconds each and need the small ones to overlap
         t.tier = SceneTier{a.order, a.order ? a.order + N : nullptr, -1, V, serp};
         t.Vl = V;
-        return launch_txp_fwd_wave(t, st);
+        const int rcw = launch_txp_fwd_wave(t, st);
+        evl.mark();
+        return rcw;
     }
     return STG_OK;
 }

@@ -38,9 +38,15 @@ __global__ __launch_bounds__(256) void nll_fwd_kernel(
             const float num = expf(-z / (2.f * om));
             const float den = 2.f * 3.14159265358979323846f * (sxsy * sqrtf(om));
             const float pdf = num / den;
-            const bool live = pdf > 1e-20f;            // torch.clamp(min=eps) passes gradient iff x > eps
-            acc += -logf(live ? pdf : 1e-20f);
-            if (gn && live) {
+            // torch.clamp(min=eps) passes the gradient iff x >= eps.  A NaN pdf (tanh saturated to rho = +-1:
+            // 1 - rho^2 = 0, 0/0) is NOT clamped by torch: the loss and the element's five gradients become NaN
+            // there, so a diverged run shows up instead of training on a silent finite 46.05
+            const bool nan = pdf != pdf;
+            const bool live = pdf >= 1e-20f;
+            acc += nan ? pdf : -logf(live ? pdf : 1e-20f);
+            if (gn && nan) {
+                g0 = g1 = g2 = g3 = g4 = pdf;
+            } else if (gn && live) {
                 const float qq = (dx * dy) / sxsy;
                 g0 = -(dx / (sx * sx) - rho * dy / sxsy) / om;
                 g1 = -(dy / (sy * sy) - rho * dx / sxsy) / om;

@@ -237,10 +237,14 @@ __device__ __forceinline__ void fwd_layer(const float (&wreg)[CINL * 9 / 4], con
 // every scene.
 
 // diagnostic stamps (never read by the kernel; only with STG_STAMPS=1)
+#ifdef STG_DIAG
 #define STG_STAMP(k)                                                                         \
     do {                                                                                     \
         if (a.stamps && (threadIdx.x & 63) == 0) a.stamps[(int64_t)n * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#else
+#define STG_STAMP(k) do { } while (0)
+#endif
 
 // zero one row slot (SW floats) of every channel of the in-place plane
 __device__ __forceinline__ void zero_row_slot(float *buf, int slot_row, int SW, int SC) {
@@ -394,7 +398,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
         const bool is_out = l == L.L;
         constexpr int U = 4;
         float slope_acc = 0.f;
-        if (a.debug_skip & 512) {
+        if (STG_SKIP(a, 512)) {
         } else if (is_out) {
             // dz of the output conv is dy: (C*P) rows of V floats, vi valid -> plane interior.  Lanes are laid over
             // (sub-row, w) with the row length rounded up to a power of two: no division by the runtime vi
@@ -468,7 +472,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
             if (lane == 0) slope_row[l] = slope_acc;
         }
         __builtin_amdgcn_wave_barrier();
-        if (a.debug_skip & 1024) {
+        if (STG_SKIP(a, 1024)) {
         } else if (l == 0) {
             float w8[27];
             load_w_bwd<T>(Pm + L.txp_w[0], w8);
@@ -815,11 +819,8 @@ static int wave_wpb(size_t per_wave) {
     // 4 waves per workgroup: the LDS footprint then admits either one workgroup (forward: 4 waves per CU,
     // one per SIMD) or two (backward: 8 per CU, two per SIMD) -- BALANCED over the four SIMDs.  Odd
     // residencies (6 waves per CU) measured 1.5x slower per wave (tools/micro/conv_tile_bench.hip).
-    int wpb = 4;
-    if (const char *e = getenv("STG_TXP_WPB")) {
-        const int w = atoi(e);
-        if (w == 1 || w == 2 || w == 4 || w == 8) wpb = w;
-    }
+    int wpb = diag_env("STG_TXP_WPB", 4);
+    if (wpb != 1 && wpb != 2 && wpb != 8) wpb = 4;
     while (wpb > 1 && per_wave * wpb > (size_t)kLdsBytes) wpb >>= 1;
     return wpb;
 }
@@ -839,8 +840,7 @@ static int wave_grid(size_t lds, int wpb, int N) {
 
 bool txp_wave_fits(const ModelLayout &L, int V) {
     if (L.n_txp < 1 || L.n_blocks != 1) return false;
-    if (const char *e = getenv("STG_NO_WAVE_PATH"))
-        if (atoi(e)) return false;
+    if (L.flags & STG_OPT_WG_PATH) return false;
     const size_t fwd = (size_t)2 * plane_slot(V) * sizeof(float);
     return fwd <= 48 * 1024;        // at least three waves per CU
 }
@@ -853,7 +853,7 @@ constexpr int kMixSmallV = 32;
 template <typename F>
 static bool mix_geom(F pw, int V, bool sorted, MixGeom *g) {
     g->on = 0;
-    if (getenv("STG_NO_MIX") && atoi(getenv("STG_NO_MIX"))) return false;
+    if (diag_env("STG_NO_MIX", 0)) return false;
     if (!sorted || V <= kMixSmallV) return false;
     const size_t block = 4 * pw(kMixSmallV);
     if (pw(V) > block || block * sizeof(float) > (size_t)kLdsBytes) return false;

@@ -167,27 +167,56 @@ class FlatPack:
         return self.flat
 
 
+# Launch options of the fused model entry points (stg_model_desc.flags / .wg_waves).  Host-side switches: the
+# library itself reads no environment and keeps no state, every choice travels in the descriptor.
+#   wg_path     run the workgroup-per-scene kernels even where the wave-per-scene path fits (tests cover both)
+#   split_bf16  TXP input-gradient GEMMs on bf16 MFMAs with hi/lo-split operands (opt-in, fp32 in / out)
+#   wg_waves    0 = auto, or 1 / 2 / 4 / 8 waves per scene in the workgroup-per-scene kernels
+OPTIONS = {"wg_path": False, "split_bf16": False, "wg_waves": 0}
+
+
 def make_desc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, use_mdn, training,
               eps=1e-5, momentum=0.1):
+    flags = (_lib.OPT_WG_PATH if OPTIONS["wg_path"] else 0) | (_lib.OPT_SPLIT_BF16 if OPTIONS["split_bf16"] else 0)
     return ModelDesc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, 1 if use_mdn else 0,
-                     1 if training else 0, eps, momentum)
+                     1 if training else 0, eps, momentum, flags, int(OPTIONS["wg_waves"]))
 
 
 class KernelTimer:
-    """HIP-event pairs around the fused forward / backward launches on the stream the kernels run on
-    (torch's current stream).  Enabled by bench.py for the roofline leg; off by default."""
+    """Per-kernel device time of the fused forward / backward entry points: HIP events recorded by the library
+    itself on the launch stream between its kernels (`events` argument of stg_model_fwd / stg_model_bwd).
+    Enabled by bench.py for the roofline leg; off by default."""
+    MAX_KERNELS = 8
 
     def __init__(self):
-        self.events = {"model_fwd": [], "model_bwd": []}
+        self.calls = {"model_fwd": [], "model_bwd": []}
 
-    def bracket(self, name):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.events[name].append((a, b))
-        return a, b
+    def events(self, name):
+        ev = _lib.HipEvents(self.MAX_KERNELS + 1)
+        self.calls[name].append(ev)
+        return ev
+
+    def kernel_ms(self, name):
+        """mean duration (ms) of the k-th kernel of entry point `name` over the recorded calls; events the entry
+        point did not reach are dropped (their interval cannot be read)."""
+        rows = []
+        for ev in self.calls[name]:
+            row = []
+            hip = ev.hip()
+            hip.hipEventSynchronize(ev.arr[0])
+            for k in range(1, ev.n):
+                ms = ctypes.c_float()
+                if hip.hipEventElapsedTime(ctypes.byref(ms), ev.arr[k - 1], ev.arr[k]) != 0:
+                    break
+                row.append(ms.value)
+            rows.append(row)
+        if not rows:
+            return []
+        n = min(len(r) for r in rows)
+        return [sum(r[k] for r in rows) / len(rows) for k in range(n)]
 
     def mean_ms(self, name):
-        ev = self.events[name]
-        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
+        return sum(self.kernel_ms(name))
 
 
 TIMER = None
@@ -210,7 +239,8 @@ class _FusedModel(torch.autograd.Function):
         adj_c, a_sn = _adj_layout(adj, n, t, v)
         peds = peds_arg(num_peds, n, x.device)
         training = desc.bn_mode == 1
-        need_grad = any(ctx.needs_input_grad)
+        # (needs_input_grad reflects requires_grad, not the grad mode: under no_grad nothing is saved)
+        need_grad = torch.is_grad_enabled() and any(ctx.needs_input_grad)
         out_t = desc.t_pred if desc.n_txpcnn > 0 else desc.t_obs
         y = torch.empty((n, desc.c_out, out_t, v), device=x.device, dtype=torch.float32)
         ws = None
@@ -232,14 +262,11 @@ class _FusedModel(torch.autograd.Function):
             global LAST_FWD_SCRATCH
             LAST_FWD_SCRATCH = scr          # diagnostics only (STG_STAMPS=1 reads the stamp tail)
         sn, sc, st, sv = x.stride()
-        ev = TIMER.bracket("model_fwd") if TIMER is not None else None
-        if ev:
-            ev[0].record()
+        ev = TIMER.events("model_fwd") if TIMER is not None else None
         check(L.stg_model_fwd(ctypes.byref(desc), ptr(flat_params), ptr(flat_buffers), ptr(x), sn, sc, st, sv,
-                              ptr(adj_c), a_sn, ptr(peds), n, v, ptr(y), ptr(ws), ptr(stats), ptr(scr), stream_ptr()),
+                              ptr(adj_c), a_sn, ptr(peds), n, v, ptr(y), ptr(ws), ptr(stats), ptr(scr),
+                              ev.arr if ev else None, ev.n if ev else 0, stream_ptr()),
               "stg_model_fwd")
-        if ev:
-            ev[1].record()
         if training:
             arr = (ctypes.c_void_p * len(nbt))(*[b.data_ptr() for b in nbt])
             # nbt[k] counts forwards of BatchNorm k; buffers are interleaved (mean, var) per BatchNorm, the
@@ -273,14 +300,10 @@ class _FusedModel(torch.autograd.Function):
         grad = torch.empty(np_, device=x.device, dtype=torch.float32)
         dx = torch.empty((n, cin, t, v), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         sn, sc, st, sv = x.stride()
-        ev = TIMER.bracket("model_bwd") if TIMER is not None else None
-        if ev:
-            ev[0].record()
+        ev = TIMER.events("model_bwd") if TIMER is not None else None
         check(L.stg_model_bwd(ctypes.byref(desc), ptr(ctx.flat_params), ptr(ctx.flat_buffers), ptr(x), sn, sc, st,
                               sv, ptr(adj_c), ctx.a_sn, ptr(peds), n, v, ptr(dy), ptr(ws), ptr(slabs), ptr(grad),
-                              ptr(dx), stream_ptr()), "stg_model_bwd")
-        if ev:
-            ev[1].record()
+                              ptr(dx), ev.arr if ev else None, ev.n if ev else 0, stream_ptr()), "stg_model_bwd")
         grads = []
         off = 0
         for i, shp in enumerate(ctx.shapes):

@@ -220,6 +220,30 @@ def test_bivariate_loss_golden(dev):
     assert np.all(grad[0, 0] == 0)
 
 
+def test_bivariate_loss_propagates_nan_like_torch(dev):
+    """|corr logit| > 10: tanh saturates to rho = +-1, 1 - rho^2 = 0 and the pdf is 0/0.  torch.clamp does not clamp a
+    NaN, so the reference's loss and that element's five gradients are NaN (a diverged run is visible); every other
+    element keeps its finite gradient.  Checked against the oracle (metrics.py:84-113 restated on torch ops)."""
+    from social_stgcnn_amd.metrics import bivariate_loss
+    O = _oracle()
+    gen = torch.Generator().manual_seed(3)
+    vp = torch.randn(12, 4, 5, generator=gen) * 0.3
+    vt = torch.randn(12, 4, 2, generator=gen)
+    vp[0, 0, 4], vp[5, 2, 4] = 20.0, -20.0
+    ref = vp.clone().requires_grad_(True)
+    l_ref = O.bivariate_loss(ref, vt)
+    l_ref.backward()
+    assert torch.isnan(l_ref)
+    got = vp.clone().to(dev).requires_grad_(True)
+    loss = bivariate_loss(got, vt.to(dev))
+    loss.backward()
+    assert torch.isnan(loss)
+    g, r = got.grad.cpu().numpy(), ref.grad.numpy()
+    assert np.array_equal(np.isnan(g), np.isnan(r)) and np.isnan(g).sum() == 10
+    ok = ~np.isnan(r)
+    assert np.abs(g[ok] - r[ok]).max() < 2e-6 * max(1.0, np.abs(r[ok]).max())
+
+
 def test_bivariate_loss_batched(dev):
     from social_stgcnn_amd.metrics import bivariate_loss
     O = _oracle()
@@ -352,12 +376,15 @@ def test_batched_ragged_train_step_vs_oracle(dev):
             assert int(val) == int(work[k]), k
 
 
+@pytest.mark.parametrize("wg_path", (False, True))
 @pytest.mark.parametrize("waves", (1, 2, 4, 8))
-def test_wave_count_variants_agree(dev, waves, monkeypatch):
-    """Every WAVES instantiation of the fused kernels computes the same scene."""
+def test_wave_count_variants_agree(dev, waves, wg_path, monkeypatch):
+    """Every WAVES instantiation of the workgroup-per-scene kernels (stg_model_desc.wg_waves) computes the same
+    scene, on the wave-per-scene path (its st_gcn block kernels) and with the whole model on the workgroup path."""
     from social_stgcnn_amd.metrics import bivariate_loss
-    monkeypatch.setenv("STG_FWD_WAVES", str(waves))
-    monkeypatch.setenv("STG_BWD_WAVES", str(waves))
+    from social_stgcnn_amd import ops
+    monkeypatch.setitem(ops.OPTIONS, "wg_waves", waves)
+    monkeypatch.setitem(ops.OPTIONS, "wg_path", wg_path)
     t, m, x, A, tgt = _train_case(dev, 17)
     y, _ = m(x, A)
     loss = bivariate_loss(y.permute(0, 2, 3, 1).squeeze(0), tgt)
@@ -467,13 +494,13 @@ def _synthetic_scene(v, seed):
 @pytest.mark.parametrize("v,force_generic", [(128, False), (96, False), (17, True), (57, True), (68, False), (69, False)])
 def test_large_v_and_workgroup_path(dev, v, force_generic, monkeypatch):
     """cfg5-style dense crowds (V=128 needs the workgroup-per-scene kernels: 8 waves, ~110 KB of LDS) and the
-    workgroup-per-scene path forced on small scenes (STG_NO_WAVE_PATH) -- forward, loss, every gradient and
+    workgroup-per-scene path forced on small scenes (ops.OPTIONS["wg_path"]) -- forward, loss, every gradient and
     the BatchNorm buffers against the oracle; 68 / 69 straddle the limit of the wave-per-scene path."""
     from social_stgcnn_amd import ops
     from social_stgcnn_amd.metrics import bivariate_loss
     O = _oracle()
     if force_generic:
-        monkeypatch.setenv("STG_NO_WAVE_PATH", "1")
+        monkeypatch.setitem(ops.OPTIONS, "wg_path", True)
     n = 3
     rels = [_synthetic_scene(v, 100 + v + i) for i in range(n)]
     m = _model(dev, seed=v).train()
@@ -506,7 +533,9 @@ def test_large_v_and_workgroup_path(dev, v, force_generic, monkeypatch):
     assert _maxdiff(losses.detach().cpu().numpy(), torch.stack(ref_losses).detach().numpy()) < 5e-5
     errs = _grad_errors(((name, p.grad) for name, p in m.named_parameters()),
                         lambda name: None if params[name].grad is None else params[name].grad.numpy())
-    bad = {k: e for k, e in errs.items() if e > 5e-4}
+    print("V=%d%s: worst relative gradient error %.1e" % (v, " (workgroup path)" if force_generic else "",
+                                                          max(errs.values())))
+    bad = {k: e for k, e in errs.items() if e > 2e-4}
     assert not bad, bad
     for k, val in m.state_dict().items():
         if "running" in k:
@@ -697,17 +726,21 @@ def test_every_crowd_size_of_the_wave_path(dev):
         assert _maxdiff(losses.detach().cpu().numpy(), torch.stack(ref_losses).detach().numpy()) < 5e-5, v
         errs = _grad_errors(((name, p.grad) for name, p in m.named_parameters()),
                             lambda name: None if params[name].grad is None else params[name].grad.numpy())
-        bad = {k: e for k, e in errs.items() if e > 1e-3}
+        bad = {k: e for k, e in errs.items() if e > 2e-4}
         assert not bad, (v, bad)
         worst[v] = max(errs.values())
-    assert max(worst.values()) < 1e-3
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    print("crowd-size sweep 1..70, worst relative gradient error vs the fp64 oracle:",
+          ", ".join("V=%d %.1e" % kv for kv in top))
+    assert max(worst.values()) < 2e-4
 
 
 def test_split_bf16_input_gradient_variant(dev, monkeypatch):
-    """STG_BWD_BF16=1 (opt-in): the input-gradient GEMMs on bf16 MFMAs with hi/lo-split operands
+    """ops.OPTIONS["split_bf16"] (opt-in, STG_OPT_SPLIT_BF16): the input-gradient GEMMs on bf16 MFMAs with hi/lo-split operands
     (hi*hi + hi*lo + lo*hi, fp32 accumulate).  Same checks, same tolerances as the fp32 path: the ragged batch against
     the oracle, the golden forward/backward cases, and a V sweep subset against the fp64 oracle."""
-    monkeypatch.setenv("STG_BWD_BF16", "1")
+    from social_stgcnn_amd import ops
+    monkeypatch.setitem(ops.OPTIONS, "split_bf16", True)
     test_batched_ragged_train_step_vs_oracle(dev)
     for v in (3, 17, 57):
         test_train_forward_backward_golden(dev, v)
