@@ -144,7 +144,8 @@ int stg_model_fwd(const stg_model_desc *d, const float *params, const float *buf
  * events[0] on `stream` before its first kernel and events[k] after its k-th kernel, as far as n_events reaches
  * (stg_model_fwd / stg_model_bwd kernel order: see DESIGN.md section 5).                                      */
 /* dy like y.  grad_params (param_count) is OVERWRITTEN with the gradient summed over the batch;
- * dx (N,c_in,t_obs,V) may be NULL.  scratch: stg_model_bwd_scratch_floats floats, 16-byte aligned
+ * dx (N,c_in,t_obs,V) may be NULL (the reference never needs it: x is data); a non-NULL dx needs STG_OPT_WG_PATH in
+ * the descriptor of BOTH passes (STG_EUNSUPPORTED otherwise: the wave-per-scene kernels compute no input gradient).  scratch: stg_model_bwd_scratch_floats floats, 16-byte aligned
  * (ws must be 16-byte aligned too).                                                               */
 int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buffers,
                   const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv,

@@ -25,6 +25,7 @@
 // with num_peds the scenes are sorted by crowd size first (model_common.hpp) and the small ones run in their own,
 // denser K1 launch.
 #include "model_common.hpp"
+#include "stgcn_block.hpp"
 #include "txp_wave.hpp"
 
 namespace stg {
@@ -44,8 +45,6 @@ struct BwdArgs {
     float *dx;
     SceneTier tier;   // which scenes this launch serves (ragged batches: sorted, walked boustrophedon)
     int Vl;           // LDS geometry of the launch: >= every V_n of the tier; 0 = V
-    int stage;        // lean image: 1 = the block's saved arrays [ax|cs|g|h2|x] are staged in LDS by one DMA burst
-    const float *da0; // non-null: the TXP chain ran in txp_bwd_wave_kernel; d(block output) comes from here
     int debug_skip;   // timing-only diagnostic (STG_DEBUG_SKIP): 1 wgrad, 2 dgrad, 4 st_gcn -- wrong results
 };
 
@@ -86,32 +85,7 @@ __host__ __device__ inline int64_t wgrad_slab_base(int layer, int rows) {
     return layer == 0 ? 0 : (int64_t)rows * (wgrad_row_len(0) + (int64_t)(layer - 1) * wgrad_row_len(1));
 }
 
-constexpr int kRedMax = 32;   // widest block reduction (values)
-
 __device__ __forceinline__ void wave_dma_copy(const float *__restrict__ src, float *lds_dst, int nvec);
-
-// Sum K per-thread values over the workgroup; totals land in tot[0..K) (LDS), visible to every
-// thread on return.
-template <int K, int WAVES>
-__device__ __forceinline__ void block_reduce(float (&v)[K], float *red, float *tot) {
-    static_assert(K <= kRedMax, "reduction too wide");
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
-    __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) red[wave * K + k] = v[k];
-    }
-    __syncthreads();
-    for (int k = tid; k < K; k += WAVES * 64) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) s += red[w * K + k];
-        tot[k] = s;
-    }
-    __syncthreads();
-}
 
 // ------------------------------------------------------------------------------------------
 // TXP-CNN backward pieces
@@ -179,355 +153,6 @@ __device__ void txp_dgrad(const float *__restrict__ W, const float *dzb, float *
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// st_gcn block backward.  ds (gradient w.r.t. the block output, [C][T][vi]) is in `D` (LDS) and is
-// consumed in place.  If `dxs` != nullptr the gradient w.r.t. the block input is written there
-// ([CIN][T][vi], LDS; may alias D) -- needed for stacked blocks; `dxg` is the optional global dx.
-// ------------------------------------------------------------------------------------------
-template <int CIN, int WAVES>
-__device__ void stgcn_block_bwd(const BwdArgs &a, const float *P_, const BlockLayout &b, int n, int vi,
-                                float *D, float *H1,
-                                float *DH2, float *DB1, float *red, float *tot, float *gsm, const float *wsn,
-                                const float *xin_ws /* block input saved by the previous block, or null */,
-                                float *dxs, float *dxg, const float *lds_saved /* staged [ax|cs|g|h2] or null */) {
-    constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, NT = WAVES * 64, TP = T + 2;
-    const int tid = threadIdx.x, V = a.V, cnt = T * vi;
-    const bool train = a.lay.bn_mode == 1;
-    const float inv_cnt = 1.0f / (float)cnt;
-    const float *wsa = wsn + a.lay.ws_hdr_floats;     // saved arrays sit behind the header
-    const float *w_ax = wsa + (int64_t)b.ws_ax * V, *w_cs = wsa + (int64_t)b.ws_cs * V;
-    const float *w_g = wsa + (int64_t)b.ws_g * V, *w_h2 = wsa + (int64_t)b.ws_h2 * V;
-    if (lds_saved) {      // the kernel staged the four arrays into LDS with one DMA burst (compact, 4-float padded)
-        const int n_ax = (CIN * T * vi + 3) & ~3, n_cs = (T * vi + 3) & ~3, n_g = (C * T * vi + 3) & ~3;
-        w_ax = lds_saved;
-        w_cs = w_ax + n_ax;
-        w_g = w_cs + n_cs;
-        w_h2 = w_g + n_g;
-    }
-    const float *hdr = wsn + b.ws_hdr;
-    float m1[C], r1[C], m2[C], r2[C], mr[C], rr[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        m1[c] = hdr[c]; r1[c] = hdr[C + c]; m2[c] = hdr[2 * C + c];
-        r2[c] = hdr[3 * C + c]; mr[c] = hdr[4 * C + c]; rr[c] = hdr[5 * C + c];
-    }
-    const float *xn = a.x + n * a.x_sn;
-    auto load_x = [&](int ci, int t, int w) -> float {
-        return xin_ws ? xin_ws[(ci * T + t) * vi + w] : xn[ci * a.x_sc + t * a.x_st + w * a.x_sv];
-    };
-
-    // ---- B1: du = ds * prelu'(u); BatchNorm tcn.3 / residual.1 reductions; h1 = prelu(bn1(g)) ----
-    {
-        float s[3 * C + 1];
-#pragma unroll
-        for (int k = 0; k < 3 * C + 1; ++k) s[k] = 0.f;
-        const float ao = P_[b.prelu_o], a1 = P_[b.prelu1];
-        // loop-invariant parameters into registers once per pass (the compiler cannot hoist them itself:
-        // params may alias the kernel's stores)
-        float g2[C], b2[C], gr[C], br[C], g1[C], b1p[C], rb[C], rw[C * CIN];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            g2[c] = P_[b.bn2_g + c]; b2[c] = P_[b.bn2_b + c]; g1[c] = P_[b.bn1_g + c]; b1p[c] = P_[b.bn1_b + c];
-            gr[c] = b.residual == 2 ? P_[b.bnr_g + c] : 0.f;
-            br[c] = b.residual == 2 ? P_[b.bnr_b + c] : 0.f;
-            rb[c] = b.residual == 2 ? P_[b.res_b + c] : 0.f;
-#pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) rw[c * CIN + ci] = b.residual == 2 ? P_[b.res_w + c * CIN + ci] : 0.f;
-        }
-        // zero rows of the t-padded h1 plane
-        for (int e = tid; e < C * vi; e += NT) {
-            const int c = e / vi, w = e - c * vi;
-            H1[(c * TP) * vi + w] = 0.f;
-            H1[(c * TP + T + 1) * vi + w] = 0.f;
-        }
-        for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
-            float xv[CIN];
-            if (b.residual != 0) {
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) xv[ci] = load_x(ci, t, w);
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int i = (c * T + t) * vi + w;
-                const float x2 = (w_h2[i] - m2[c]) * r2[c];
-                float u = fmaf(x2, g2[c], b2[c]);
-                float xr = 0.f;
-                if (b.residual == 2) {
-                    float r = rb[c];
-#pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) r = fmaf(rw[c * CIN + ci], xv[ci], r);
-                    xr = (r - mr[c]) * rr[c];
-                    u += fmaf(xr, gr[c], br[c]);
-                } else if (b.residual == 1) {
-                    if (CIN == C) u += xv[c % CIN];
-                }
-                const float ds = D[i];
-                float du = ds;
-                if (!a.lay.use_mdn && !(u > 0.f)) {
-                    du = ao * ds;
-                    s[3 * C] = fmaf(ds, u, s[3 * C]);
-                }
-                D[i] = du;
-                s[c] += du;
-                s[C + c] = fmaf(du, x2, s[C + c]);
-                s[2 * C + c] = fmaf(du, xr, s[2 * C + c]);
-                // h1 for the temporal-conv weight gradient
-                const float b1 = fmaf((w_g[i] - m1[c]) * r1[c], g1[c], b1p[c]);
-                H1[(c * TP + t + 1) * vi + w] = b1 > 0.f ? b1 : a1 * b1;
-            }
-        }
-        block_reduce<3 * C + 1, WAVES>(s, red, tot);
-        for (int k = tid; k < 3 * C + 1; k += NT) {
-            const float v = tot[k];
-            if (k < C) {
-                gsm[b.bn2_b + k] += v;
-                if (b.residual == 2) gsm[b.bnr_b + k] += v;
-            } else if (k < 2 * C) {
-                gsm[b.bn2_g + k - C] += v;
-            } else if (k < 3 * C) {
-                if (b.residual == 2) gsm[b.bnr_g + k - 2 * C] += v;
-            } else {
-                gsm[b.prelu_o] += v;
-            }
-        }
-    }
-    float mdu[C], mdx2[C], mdxr[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        mdu[c] = train ? tot[c] * inv_cnt : 0.f;
-        mdx2[c] = train ? tot[C + c] * inv_cnt : 0.f;
-        mdxr[c] = train ? tot[2 * C + c] * inv_cnt : 0.f;
-    }
-    // ---- B2: dh2, dr; residual 1x1 conv gradients ------------------------------------------------
-    {
-        constexpr int K2 = C * CIN + C;
-        float s[K2];
-#pragma unroll
-        for (int k = 0; k < K2; ++k) s[k] = 0.f;
-        float g2[C], gr[C], rb[C], rw[C * CIN];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            g2[c] = P_[b.bn2_g + c];
-            gr[c] = b.residual == 2 ? P_[b.bnr_g + c] : 0.f;
-            rb[c] = b.residual == 2 ? P_[b.res_b + c] : 0.f;
-#pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) rw[c * CIN + ci] = b.residual == 2 ? P_[b.res_w + c * CIN + ci] : 0.f;
-        }
-        for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
-            float xv[CIN];
-            if (b.residual == 2) {
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) xv[ci] = load_x(ci, t, w);
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int i = (c * T + t) * vi + w;
-                const float du = D[i];
-                const float x2 = (w_h2[i] - m2[c]) * r2[c];
-                DH2[(c * TP + t + 1) * vi + w] = g2[c] * r2[c] * (du - mdu[c] - x2 * mdx2[c]);
-                if (b.residual == 2) {
-                    float r = rb[c];
-#pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) r = fmaf(rw[c * CIN + ci], xv[ci], r);
-                    const float xr = (r - mr[c]) * rr[c];
-                    const float dr = gr[c] * rr[c] * (du - mdu[c] - xr * mdxr[c]);
-#pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) s[c * CIN + ci] = fmaf(dr, xv[ci], s[c * CIN + ci]);
-                    s[C * CIN + c] += dr;
-                }
-            }
-        }
-        for (int e = tid; e < C * vi; e += NT) {
-            const int c = e / vi, w = e - c * vi;
-            DH2[(c * TP) * vi + w] = 0.f;
-            DH2[(c * TP + T + 1) * vi + w] = 0.f;
-        }
-        if (b.residual == 2) {
-            block_reduce<K2, WAVES>(s, red, tot);
-            for (int k = tid; k < K2; k += NT) {
-                if (k < C * CIN) gsm[b.res_w + k] += tot[k];
-                else gsm[b.res_b + k - C * CIN] += tot[k];
-            }
-        } else {
-            __syncthreads();
-        }
-    }
-    // ---- B3a: temporal conv weight gradients, one temporal tap at a time (25 accumulators, not 75) -------
-    for (int dt = 0; dt < KT; ++dt) {
-        float s[C * C];
-#pragma unroll
-        for (int k = 0; k < C * C; ++k) s[k] = 0.f;
-        for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
-            float dh[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) dh[c] = DH2[(c * TP + t + 1) * vi + w];
-#pragma unroll
-            for (int ci = 0; ci < C; ++ci) {
-                // h1 at t + dt - 1 (t-padded plane, rows 0 and T+1 are zero)
-                const float hv = H1[(ci * TP + t + dt) * vi + w];
-#pragma unroll
-                for (int c = 0; c < C; ++c) s[c * C + ci] = fmaf(dh[c], hv, s[c * C + ci]);
-            }
-        }
-        block_reduce<C * C, WAVES>(s, red, tot);
-        for (int k = tid; k < C * C; k += NT) gsm[b.tcn_w + k * KT + dt] += tot[k];
-    }
-    // ---- B3b: dh1 -> db1, conv bias gradient, BatchNorm tcn.0 reductions, PReLU slope ---------------------
-    {
-        constexpr int K3 = 3 * C + 1;                  // conv bias, sum db1, sum db1*xhat1, prelu slope
-        float s[K3];
-#pragma unroll
-        for (int k = 0; k < K3; ++k) s[k] = 0.f;
-        const float a1 = P_[b.prelu1];
-        float tw[C * C * KT], g1[C], b1p[C];
-#pragma unroll
-        for (int k = 0; k < C * C * KT; ++k) tw[k] = P_[b.tcn_w + k];
-#pragma unroll
-        for (int c = 0; c < C; ++c) { g1[c] = P_[b.bn1_g + c]; b1p[c] = P_[b.bn1_b + c]; }
-        for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
-            float dh1[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                s[c] += DH2[(c * TP + t + 1) * vi + w];
-                dh1[c] = 0.f;
-            }
-            // input gradient: dh1[ci][t] = sum_{c,dt} Wt[c][ci][dt] dh2[c][t - dt + 1]
-#pragma unroll
-            for (int dt = 0; dt < KT; ++dt)
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float dv = DH2[(c * TP + t - dt + 2) * vi + w];
-#pragma unroll
-                    for (int ci = 0; ci < C; ++ci) dh1[ci] = fmaf(tw[(c * C + ci) * KT + dt], dv, dh1[ci]);
-                }
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int i = (c * T + t) * vi + w;
-                const float x1 = (w_g[i] - m1[c]) * r1[c];
-                const float b1 = fmaf(x1, g1[c], b1p[c]);
-                float db = dh1[c];
-                if (!(b1 > 0.f)) {
-                    db = a1 * dh1[c];
-                    s[3 * C] = fmaf(dh1[c], b1, s[3 * C]);
-                }
-                DB1[i] = db;
-                s[C + c] += db;
-                s[2 * C + c] = fmaf(db, x1, s[2 * C + c]);
-            }
-        }
-        block_reduce<K3, WAVES>(s, red, tot);
-        for (int k = tid; k < K3; k += NT) {
-            const float v = tot[k];
-            if (k < C) gsm[b.tcn_b + k] += v;
-            else if (k < 2 * C) gsm[b.bn1_b + k - C] += v;
-            else if (k < 3 * C) gsm[b.bn1_g + k - 2 * C] += v;
-            else gsm[b.prelu1] += v;
-        }
-    }
-    float mdb[C], mdbx[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        mdb[c] = train ? tot[C + c] * inv_cnt : 0.f;
-        mdbx[c] = train ? tot[2 * C + c] * inv_cnt : 0.f;
-    }
-    // ---- B4: dg; gcn 1x1 conv gradients; d(aggregated input) -------------------------------------
-    {
-        constexpr int K4 = C * CIN + C;
-        float s[K4];
-#pragma unroll
-        for (int k = 0; k < K4; ++k) s[k] = 0.f;
-        const bool want_dx = dxs != nullptr || dxg != nullptr;
-        float g1[C], gw[C * CIN];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            g1[c] = P_[b.bn1_g + c];
-#pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) gw[c * CIN + ci] = P_[b.gcn_w + c * CIN + ci];
-        }
-        for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
-            float axv[CIN], dax[CIN];
-#pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) {
-                axv[ci] = w_ax[(ci * T + t) * vi + w];
-                dax[ci] = 0.f;
-            }
-            const float csum = w_cs[q];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int i = (c * T + t) * vi + w;
-                const float x1 = (w_g[i] - m1[c]) * r1[c];
-                const float dg = g1[c] * r1[c] * (DB1[i] - mdb[c] - x1 * mdbx[c]);
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) {
-                    s[c * CIN + ci] = fmaf(dg, axv[ci], s[c * CIN + ci]);
-                    dax[ci] = fmaf(gw[c * CIN + ci], dg, dax[ci]);
-                }
-                s[C * CIN + c] = fmaf(dg, csum, s[C * CIN + c]);
-            }
-            if (want_dx) {
-                // stash d(ax) in the (now free) h1 plane: [CIN][T][vi]
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) H1[(ci * T + t) * vi + w] = dax[ci];
-            }
-        }
-        block_reduce<K4, WAVES>(s, red, tot);
-        for (int k = tid; k < K4; k += NT) {
-            if (k < C * CIN) gsm[b.gcn_w + k] += tot[k];
-            else gsm[b.gcn_b + k - C * CIN] += tot[k];
-        }
-        if (want_dx) {
-            // ---- B5: dx[ci][t][v] = sum_w dax[ci][t][w] A[t][v][w] + residual path -----------------
-            const float *an = a.adj + n * a.a_sn;
-            for (int q = tid; q < cnt; q += NT) {
-                const int t = q / vi, v = q - t * vi;
-                float acc[CIN];
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.f;
-                const float *arow = an + ((int64_t)t * V + v) * V;
-                for (int w = 0; w < vi; ++w) {
-                    const float av = arow[w];
-#pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) acc[ci] = fmaf(H1[(ci * T + t) * vi + w], av, acc[ci]);
-                }
-                if (b.residual == 2) {
-                    float xv[CIN];
-#pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) xv[ci] = load_x(ci, t, v);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        const int i = (c * T + t) * vi + v;
-                        float r = P_[b.res_b + c];
-#pragma unroll
-                        for (int ci = 0; ci < CIN; ++ci) r = fmaf(P_[b.res_w + c * CIN + ci], xv[ci], r);
-                        const float xr = (r - mr[c]) * rr[c];
-                        const float dr = P_[b.bnr_g + c] * rr[c] * (D[i] - mdu[c] - xr * mdxr[c]);
-#pragma unroll
-                        for (int ci = 0; ci < CIN; ++ci) acc[ci] = fmaf(P_[b.res_w + c * CIN + ci], dr, acc[ci]);
-                    }
-                } else if (b.residual == 1) {
-#pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci)
-                        if (CIN == C) acc[ci] += D[(ci * T + t) * vi + v];
-                }
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) {
-                    if (dxg) dxg[(int64_t)(ci * T + t) * V + v] = acc[ci];
-                    if (dxs) DB1[(ci * T + t) * vi + v] = acc[ci];      // staged; copied to D after the barrier
-                }
-            }
-            __syncthreads();
-            if (dxs)
-                for (int e = tid; e < CIN * cnt; e += NT) dxs[e] = DB1[e];
-            __syncthreads();
-        }
-    }
-}
-
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, const float *params) {
     // (unlike the forward kernel, params is NOT __restrict__ here: scalar-loading the weights into SGPRs pushed
@@ -540,17 +165,15 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
     const int scmax = txp_sc(Vl);
     const int plane_floats = P * scmax;
     // st_gcn phase needs 3 planes: h1 [C][T+2][V], dh2 [C][T+2][V], db1 [C][T][V]
-    const bool lean = a.da0 != nullptr && a.dx == nullptr && L.n_blocks == 1;    // blocks only, no dx
-    const int st_floats = lean ? 2 * C * (T + 2) * Vl : (2 * C * (T + 2) + C * T) * Vl;
-    const int reg_floats = lean ? st_floats : (plane_floats > st_floats ? plane_floats : st_floats);
-    const int dcur_floats = lean ? C * T * Vl : P * C * Vl;
+    const int st_floats = (2 * C * (T + 2) + C * T) * Vl;
+    const int reg_floats = plane_floats > st_floats ? plane_floats : st_floats;
+    const int dcur_floats = P * C * Vl;
     const int n_small = L.n_blk_params + L.n_txp;
     float *gsm = sm;                                  // [n_small] block parameters, then the PReLU slopes
     float *dzb = gsm + ((n_small + 3) & ~3);          // [P][SC]   dz_l, zero-bordered (aliases the st_gcn planes)
     float *dcur = dzb + reg_floats;                   // [P*C*V]   gradient w.r.t. the layer output
     float *red = dcur + dcur_floats;                  // [WAVES*kRedMax]
     float *tot = red + WAVES * kRedMax;               // [kRedMax]
-    float *saved = tot + kRedMax;                     // lean: [ax|cs|g|h2] of the scene, staged by LDS-DMA
     const float *Pm = params;
 
     for (int e = tid; e < n_small; e += NT) gsm[e] = 0.f;
@@ -576,39 +199,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
         const int out_rows = L.n_txp > 0 ? C * P : C * T;
         const float *dyn = a.dy + (int64_t)n * out_rows * V;
         __syncthreads();
-        if (a.da0) {
-            if (lean) {
-                // ONE burst of LDS-DMA brings d(a_0) and the four saved arrays of the block: the reduction passes
-                // below then run from LDS instead of paying an HBM round trip per pass
-                const BlockLayout &b0 = L.blk[0];
-                const float *wsa = wsn + L.ws_hdr_floats;
-                const int wave = tid >> 6;
-                const int n_ax = (b0.cin * T * vi + 3) & ~3, n_cs = (T * vi + 3) & ~3, n_g = (C * T * vi + 3) & ~3;
-                const float *srcs[5] = {a.da0 + (int64_t)n * (C * T * V), wsa + (int64_t)b0.ws_ax * V,
-                                        wsa + (int64_t)b0.ws_cs * V, wsa + (int64_t)b0.ws_g * V,
-                                        wsa + (int64_t)b0.ws_h2 * V};
-                float *dsts[5] = {dcur, saved, saved + n_ax, saved + n_ax + n_cs, saved + n_ax + n_cs + n_g};
-                const int cnts[5] = {n_g >> 2, n_ax >> 2, n_cs >> 2, n_g >> 2, n_g >> 2};
-                const int kmax = (!a.stage) ? 1 : 5;
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    if (k < kmax && k % WAVES == wave) wave_dma_copy(srcs[k], dsts[k], cnts[k]);
-                // the (strided) block input x[n] rides along into LDS: [cin][T][vi]
-                if (a.stage) {
-                    const float *xn = a.x + n * a.x_sn;
-                    float *xl = saved + n_ax + n_cs + 2 * n_g;
-                    for (int e = tid; e < b0.cin * T * vi; e += NT) {
-                        const int v = e % vi, ct = e / vi, t = ct % T, c = ct / T;
-                        xl[e] = xn[c * a.x_sc + t * a.x_st + v * a.x_sv];
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                const float *src = a.da0 + (int64_t)n * (C * T * V);
-                for (int e = tid; e < C * T * vi; e += NT) dcur[e] = src[e];
-            }
-            __syncthreads();
-        } else if (L.n_txp > 0) {
+        if (L.n_txp > 0) {
             // ---- TXP-CNN backward (input-gradient chain) -------------------------------------------
             for (int e = tid; e < P * SC; e += NT) dzb[e] = 0.f;
             __syncthreads();
@@ -681,22 +272,17 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
             __syncthreads();
         }
         // ---- st_gcn blocks, last to first ------------------------------------------------------
-        // lean image: db1 reuses the du plane (dcur), which is dead once dh2 / dr have been formed
-        float *H1 = dzb, *DH2 = dzb + C * (T + 2) * Vl, *DB1 = lean ? dcur : DH2 + C * (T + 2) * Vl;
+        float *H1 = dzb, *DH2 = dzb + C * (T + 2) * Vl, *DB1 = DH2 + C * (T + 2) * Vl;
         for (int j = L.n_blocks - 1; j >= 0 && !STG_SKIP(a, 4); --j) {
             const float *xin = j > 0 ? wsn + L.ws_hdr_floats + (int64_t)L.blk[j - 1].ws_s * V : nullptr;
-            if (lean && a.stage) {       // x[n] was staged behind the saved arrays
-                const int n_ax = (L.blk[0].cin * T * vi + 3) & ~3, n_cs = (T * vi + 3) & ~3, n_g = (C * T * vi + 3) & ~3;
-                xin = saved + n_ax + n_cs + 2 * n_g;
-            }
             float *dxs = j > 0 ? dcur : nullptr;
             float *dxg = j == 0 ? dxn : nullptr;
             if (L.blk[j].cin == Cfg::CIN0)
-                stgcn_block_bwd<Cfg::CIN0, WAVES>(a, params, L.blk[j], n, vi, dcur, H1, DH2, DB1, red, tot, gsm, wsn, xin,
-                                                  dxs, dxg, (lean && a.stage) ? saved : nullptr);
+                stgcn_block_bwd<Cfg::CIN0, WAVES, true>(a, params, L.blk[j], n, vi, dcur, H1, DH2, DB1, red, tot, gsm, wsn,
+                                                        xin, dxs, dxg, nullptr);
             else
-                stgcn_block_bwd<Cfg::C, WAVES>(a, params, L.blk[j], n, vi, dcur, H1, DH2, DB1, red, tot, gsm, wsn, xin, dxs,
-                                               dxg, (lean && a.stage) ? saved : nullptr);
+                stgcn_block_bwd<Cfg::C, WAVES, true>(a, params, L.blk[j], n, vi, dcur, H1, DH2, DB1, red, tot, gsm, wsn, xin,
+                                                     dxs, dxg, nullptr);
         }
     }
     __syncthreads();
@@ -995,15 +581,13 @@ static int env_waves(const char *name, int dflt) {     // (diagnostic builds onl
     return (w == 1 || w == 2 || w == 4 || w == 8) ? w : dflt;
 }
 
-static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves, bool lean = false, bool stage = true) {
+static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves) {
     const int plane = Cfg::P * txp_sc(V);
-    const int st = lean ? 2 * Cfg::C * (Cfg::T + 2) * V : (2 * Cfg::C * (Cfg::T + 2) + Cfg::C * Cfg::T) * V;
-    const int reg = lean ? st : (plane > st ? plane : st);
-    const int dcur = lean ? Cfg::C * Cfg::T * V : Cfg::P * Cfg::C * V;
+    const int st = (2 * Cfg::C * (Cfg::T + 2) + Cfg::C * Cfg::T) * V;
+    const int reg = plane > st ? plane : st;
+    const int dcur = Cfg::P * Cfg::C * V;
     const int n_small = L.n_blk_params + L.n_txp;
-    const int cin0 = L.blk[0].cin;
-    const int saved = (lean && stage) ? (cin0 + 1 + 2 * Cfg::C + cin0) * Cfg::T * V + 16 : 0;     // [ax|cs|g|h2|x] + 4-float paddings
-    const size_t fl = ((n_small + 3) & ~3) + (size_t)reg + (size_t)dcur + (size_t)waves * kRedMax + kRedMax + saved;
+    const size_t fl = ((n_small + 3) & ~3) + (size_t)reg + (size_t)dcur + (size_t)waves * kRedMax + kRedMax;
     return fl * sizeof(float);
 }
 
@@ -1011,21 +595,8 @@ static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves, bool lean = 
 // barriers in its ~15 block reductions), more waves only when a scene's rows no longer fit one wave's registers
 static int bwd_waves(const ModelLayout &L, int V) { return L.wg_waves ? L.wg_waves : (V <= 40 ? 1 : (V <= 80 ? 4 : 8)); }
 
-// lean image: stage the block's saved arrays in LDS (one DMA burst instead of an HBM round trip per pass) unless
-// that costs residency -- at V = 32 the staged image admits 4 workgroups per CU, the plain one 8 = one scene per
-// workgroup in a single round (measured 66 -> 59 us)
-static bool bwd_stage(const ModelLayout &L, int V, int waves) {
-    const int by_waves = 8 / waves > 0 ? 8 / waves : 1;
-    auto residency = [&](bool st) {
-        const size_t lds = bwd_lds_bytes(L, V, waves, true, st);
-        if (lds > (size_t)kLdsBytes) return 0;
-        const int per_cu = (int)(kLdsBytes / lds);
-        return per_cu < by_waves ? per_cu : by_waves;
-    };
-    return residency(true) >= residency(false);
-}
-static int bwd_grid_w(const ModelLayout &L, int N, int V, int waves, bool lean) {
-    const size_t lds = bwd_lds_bytes(L, V, waves, lean, lean && bwd_stage(L, V, waves));
+static int bwd_grid_w(const ModelLayout &L, int N, int V, int waves) {
+    const size_t lds = bwd_lds_bytes(L, V, waves);
     if (lds > (size_t)kLdsBytes) return -1;
     int per_cu = (int)(kLdsBytes / lds);
     const int by_waves = 8 / waves > 0 ? 8 / waves : 1;   // 256-VGPR kernel: 2 waves per SIMD
@@ -1035,14 +606,12 @@ static int bwd_grid_w(const ModelLayout &L, int N, int V, int waves, bool lean) 
     if (const int g = diag_env("STG_BWD_GRID", 0)) grid = g > 0 ? g : grid;
     return grid < N ? grid : N;
 }
-static int bwd_grid(const ModelLayout &L, int N, int V, bool lean = false) {
-    return bwd_grid_w(L, N, V, bwd_waves(L, V), lean);
-}
+static int bwd_grid(const ModelLayout &L, int N, int V) { return bwd_grid_w(L, N, V, bwd_waves(L, V)); }
 // ragged batches padded beyond kBwdTierV: the scenes up to kBwdTierV pedestrians (most of a real batch) run in a
 // second launch with ONE wave per scene and the LDS image of V = kBwdTierV; slab rows of both launches are stacked
 constexpr int kBwdTierV = 32;
-static int bwd_grid_small(const ModelLayout &L, int N, int V, bool lean) {
-    return V > kBwdTierV ? bwd_grid_w(L, N, kBwdTierV, 1, lean) : 0;
+static int bwd_grid_small(const ModelLayout &L, int N, int V) {
+    return V > kBwdTierV ? bwd_grid_w(L, N, kBwdTierV, 1) : 0;
 }
 
 // K2 launch geometry: one persistent workgroup of `waves` waves per CU slot; the chip's slots are split
@@ -1083,36 +652,34 @@ static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
     return true;
 }
 
-static int64_t bwd_scratch_floats(const ModelLayout &L, int N, int V) {
-    int g1 = bwd_grid(L, N, V);
-    if (g1 < 0) return -1;
-    if (txp_wave_fits(L, V)) {                 // the lean (blocks-only, no dx) image admits more workgroups
-        const int g2 = bwd_grid(L, N, V, true);
-        if (g2 > g1) g1 = g2;
-    }
-    int gs = bwd_grid_small(L, N, V, false);
-    if (txp_wave_fits(L, V)) {
-        const int gs2 = bwd_grid_small(L, N, V, true);
-        if (gs2 > gs) gs = gs2;
-    }
+// scratch carve of stg_model_bwd (offsets in floats):
+//   rows   small-parameter gradient rows [n_rows][n_blk_params + n_txp]: one per persistent workgroup of K1 (both
+//          launches of a two-tier ragged run), or one per SCENE on the wave-per-scene path
+//   slab2  weight-gradient slab rows of K2          dzg  dz_l hand-off [N][L][dz_slot(V)]
+//   order  sorted scene list + tier offsets (int32)
+struct BwdCarve {
+    int64_t rows, slab2, dzg, order, total;
+};
+static bool bwd_carve(const ModelLayout &L, int N, int V, BwdCarve *c, WgradGeom *wg) {
+    const int g1 = bwd_grid(L, N, V);
+    if (g1 < 0) return false;
+    int gs = bwd_grid_small(L, N, V);
     if (gs < 0) gs = 0;
-    int64_t fl = (int64_t)(g1 + gs) * (L.n_blk_params + L.n_txp);
-    fl = (fl + 3) & ~(int64_t)3;
+    int64_t n_rows = g1 + gs;
+    if (txp_wave_fits(L, V) && N > n_rows) n_rows = N;
+    c->rows = 0;
+    int64_t fl = (n_rows * (L.n_blk_params + L.n_txp) + 3) & ~(int64_t)3;
+    c->slab2 = fl;
+    c->dzg = fl;
     if (L.n_txp > 0) {
-        WgradGeom g;
-        if (!wgrad_geom(L, N, V, &g)) return -1;
-        fl += wgrad_slab_base(L.L + 1, g.rows);
-        fl = (fl + 3) & ~(int64_t)3;
-        fl += (int64_t)N * L.L * dz_slot(V);
-        if (txp_wave_fits(L, V)) {
-            fl += (int64_t)N * (Cfg::C * Cfg::T * V);            // d(a_0) hand-off
-            fl = (fl + 3) & ~(int64_t)3;
-            fl += (int64_t)N * L.n_txp;                          // per-scene PReLU slope gradients
-            fl = ((fl + 3) & ~(int64_t)3) + 4;                   // (reserved)
-        }
+        if (!wgrad_geom(L, N, V, wg)) return false;
+        fl = (fl + wgrad_slab_base(L.L + 1, wg->rows) + 3) & ~(int64_t)3;
+        c->dzg = fl;
+        fl = (fl + (int64_t)N * L.L * dz_slot(V) + 3) & ~(int64_t)3;
     }
-    fl = (fl + 3) & ~(int64_t)3;
-    return fl + order_floats(N, V);                                 // scene order of ragged batches (int32)
+    c->order = fl;
+    c->total = fl + order_floats(N, V);
+    return true;
 }
 
 }  // namespace stg
@@ -1124,9 +691,10 @@ int64_t stg_model_bwd_scratch_floats(const stg_model_desc *d, int N, int V) {
     const int rc = stg::make_layout(d, &l);
     if (rc != STG_OK) return rc;
     if (N <= 0 || V <= 0) return stg::fail(STG_EINVAL, "stg_model_bwd_scratch_floats: N=%d V=%d", N, V);
-    const int64_t fl = stg::bwd_scratch_floats(l, N, V);
-    if (fl < 0) return stg::fail(STG_ELDS, "stg_model_bwd: V=%d does not fit the LDS of one CU", V);
-    return fl;
+    stg::BwdCarve c;
+    stg::WgradGeom wg{};
+    if (!stg::bwd_carve(l, N, V, &c, &wg)) return stg::fail(STG_ELDS, "stg_model_bwd: V=%d does not fit the LDS of one CU", V);
+    return c.total;
 }
 
 int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
@@ -1152,127 +720,101 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         if (e != hipSuccess) return hip_fail(e, "stg_model_bwd: memset");
         return STG_OK;
     }
-    const bool lean = txp_wave_fits(L, V) && dx == nullptr && L.n_blocks == 1;
-    const int waves = bwd_waves(L, V);
-    const bool stage = lean && bwd_stage(L, V, waves);
-    const size_t lds = bwd_lds_bytes(L, V, waves, lean, stage);
-    STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_bwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
-                kLdsBytes);
-    const int grid = bwd_grid(L, N, V, lean);
-    const int n_small = L.n_blk_params + L.n_txp;
-    // scratch carve (must match bwd_scratch_floats)
-    float *slab1 = scratch;
-    int64_t off;
-    {
-        int g1 = bwd_grid(L, N, V), gs = bwd_grid_small(L, N, V, false);
-        if (txp_wave_fits(L, V)) {
-            const int g2 = bwd_grid(L, N, V, true), gs2 = bwd_grid_small(L, N, V, true);
-            if (g2 > g1) g1 = g2;
-            if (gs2 > gs) gs = gs2;
-        }
-        if (gs < 0) gs = 0;
-        off = ((int64_t)(g1 + gs) * n_small + 3) & ~(int64_t)3;
-    }
-    float *slab2 = scratch + off;
+    BwdCarve cv;
     WgradGeom wg{};
-    float *dzg = nullptr;
-    if (L.n_txp > 0) {
-        STG_REQUIRE(wgrad_geom(L, N, V, &wg), STG_ELDS, "stg_model_bwd: V=%d does not fit LDS (wgrad)", V);
-        off += wgrad_slab_base(L.L + 1, wg.rows);
-        off = (off + 3) & ~(int64_t)3;
-        dzg = scratch + off;
-        off += (int64_t)N * L.L * dz_slot(V);
-    }
+    STG_REQUIRE(bwd_carve(L, N, V, &cv, &wg), STG_ELDS, "stg_model_bwd: V=%d does not fit the LDS of one CU", V);
+    const int n_small = L.n_blk_params + L.n_txp;
+    float *rows = scratch + cv.rows, *slab2 = scratch + cv.slab2;
+    float *dzg = L.n_txp > 0 ? scratch + cv.dzg : nullptr;
+    // the wave-per-scene kernels compute no input gradient (the reference never needs one: x is data), and their
+    // saved pre-activations are laid out for themselves: a caller that wants dx runs BOTH passes on the workgroup
+    // kernels (STG_OPT_WG_PATH in the descriptor)
     const bool wave_path = txp_wave_fits(L, V);
-    float *da0 = nullptr, *slopes = nullptr;
-    if (wave_path) {
-        da0 = scratch + off;
-        off += (int64_t)N * (Cfg::C * Cfg::T * V);
-        off = (off + 3) & ~(int64_t)3;
-        slopes = scratch + off;
-    }
+    STG_REQUIRE(!(wave_path && dx), STG_EUNSUPPORTED,
+                "stg_model_bwd: dx is only computed by the workgroup-per-scene kernels: set STG_OPT_WG_PATH in the "
+                "descriptor of the forward and the backward call");
     a.params = params; a.buffers = buffers; a.x = x;
     a.x_sn = x_sn; a.x_sc = x_sc; a.x_st = x_st; a.x_sv = x_sv;
     a.adj = adj; a.a_sn = a_sn; a.num_peds = num_peds; a.N = N; a.V = V;
-    a.dy = dy; a.ws = ws; a.ws_stride = ws_floats_per_scene(L, V); a.slab1 = slab1; a.dzg = dzg; a.dx = dx;
-    a.stage = stage;
-    // ragged batch: sorted scene list at the tail of the scratch buffer (see bwd_scratch_floats)
-    int32_t *order = reinterpret_cast<int32_t *>(scratch + bwd_scratch_floats(L, N, V) - order_floats(N, V));
+    a.dy = dy; a.ws = ws; a.ws_stride = ws_floats_per_scene(L, V); a.slab1 = rows; a.dzg = dzg; a.dx = dx;
+    // ragged batch: sorted scene list at the tail of the scratch buffer
+    int32_t *order = reinterpret_cast<int32_t *>(scratch + cv.order);
     const bool sorted = launch_scene_order(num_peds, N, V, order, order + N, st);
     const int serp = diag_env("STG_WALK", 1);
     a.tier = SceneTier{sorted ? order : nullptr, sorted ? order + N : nullptr, -1, V, serp};
     a.debug_skip = diag_env("STG_DEBUG_SKIP", 0);
+    int slab_rows;
     if (wave_path) {
+        // K1 (wave per scene): TXP input-gradient chain + st_gcn block backward; one small-gradient row per scene
         TxpBwdArgs t{};
         t.lay = L; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V; t.dy = dy; t.ws = ws;
-        t.ws_stride = a.ws_stride; t.dzg = dzg; t.da0 = da0; t.slopes = slopes;
+        t.x = x; t.x_sn = x_sn; t.x_sc = x_sc; t.x_st = x_st; t.x_sv = x_sv; t.adj = adj; t.a_sn = a_sn;
+        t.ws_stride = a.ws_stride; t.dzg = dzg; t.rows = rows;
         t.tier = a.tier;
         t.Vl = V;
         t.debug_skip = a.debug_skip;
         t.split_bf16 = (L.flags & STG_OPT_SPLIT_BF16) ? 1 : 0;
-        if (!STG_SKIP(a, 2)) {
-            const int rcw = launch_txp_bwd_wave(t, st);
-            if (rcw != STG_OK) return rcw;
-        }
-        evl.mark();
-        a.da0 = da0;
-    }
+        const int rcw = launch_txp_bwd_wave(t, st);
+        if (rcw != STG_OK) return rcw;
+        slab_rows = N;
+    } else {
+        const int waves = bwd_waves(L, V);
+        const size_t lds = bwd_lds_bytes(L, V, waves);
+        STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_bwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
+                    kLdsBytes);
+        const int grid = bwd_grid(L, N, V);
 #define STG_LAUNCH_BWD(W)                                                                                    \
     do {                                                                                                     \
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&model_bwd_kernel<W>),            \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
         if (e_ != hipSuccess) return hip_fail(e_, "stg_model_bwd: hipFuncSetAttribute");                     \
-        hipLaunchKernelGGL(model_bwd_kernel<W>, dim3(grid), dim3(W * 64), lds, st, a, params);                       \
+        hipLaunchKernelGGL(model_bwd_kernel<W>, dim3(grid), dim3(W * 64), lds, st, a, params);               \
     } while (0)
-    int slab_rows = grid;
-    if (a.tier.order && bwd_grid_small(L, N, V, lean) > 0) {
-        // large scenes: `waves` per scene, slab rows [0, grid); small scenes: one wave per scene with the LDS image
-        // (and so the residency) of V = kBwdTierV, slab rows behind them
-        a.tier.v_lo = kBwdTierV;
-        switch (waves) {
-            case 1: STG_LAUNCH_BWD(1); break;
-            case 2: STG_LAUNCH_BWD(2); break;
-            case 4: STG_LAUNCH_BWD(4); break;
-            default: STG_LAUNCH_BWD(8); break;
+        slab_rows = grid;
+        if (a.tier.order && bwd_grid_small(L, N, V) > 0) {
+            // large scenes: `waves` per scene, slab rows [0, grid); small scenes: one wave per scene with the LDS image
+            // (and so the residency) of V = kBwdTierV, slab rows behind them
+            a.tier.v_lo = kBwdTierV;
+            switch (waves) {
+                case 1: STG_LAUNCH_BWD(1); break;
+                case 2: STG_LAUNCH_BWD(2); break;
+                case 4: STG_LAUNCH_BWD(4); break;
+                default: STG_LAUNCH_BWD(8); break;
+            }
+            STG_LAUNCH_CHECK("stg_model_bwd: K1 (large scenes)");
+            const int grid_hi = grid;
+            {
+                const int grid = bwd_grid_small(L, N, V);
+                const size_t lds = bwd_lds_bytes(L, kBwdTierV, 1);
+                a.Vl = kBwdTierV;
+                a.tier.v_lo = -1; a.tier.v_hi = kBwdTierV;
+                a.slab1 = rows + (int64_t)grid_hi * n_small;
+                STG_LAUNCH_BWD(1);
+                slab_rows = grid_hi + grid;
+            }
+            a.slab1 = rows;
+            a.Vl = 0;
+            a.tier.v_lo = -1; a.tier.v_hi = V;
+        } else {
+            switch (waves) {
+                case 1: STG_LAUNCH_BWD(1); break;
+                case 2: STG_LAUNCH_BWD(2); break;
+                case 4: STG_LAUNCH_BWD(4); break;
+                default: STG_LAUNCH_BWD(8); break;
+            }
         }
-        STG_LAUNCH_CHECK("stg_model_bwd: K1 (large scenes)");
-        const int grid_hi = grid;
-        {
-            const int grid = bwd_grid_small(L, N, V, lean);
-            const bool stage_s = lean && bwd_stage(L, kBwdTierV, 1);
-            const size_t lds = bwd_lds_bytes(L, kBwdTierV, 1, lean, stage_s);
-            a.Vl = kBwdTierV;
-            a.stage = stage_s;
-            a.tier.v_lo = -1; a.tier.v_hi = kBwdTierV;
-            a.slab1 = slab1 + (int64_t)grid_hi * n_small;
-            STG_LAUNCH_BWD(1);
-            slab_rows = grid_hi + grid;
-        }
-        a.slab1 = slab1;
-        a.Vl = 0;
-        a.stage = stage;
-    } else {
-        switch (waves) {
-            case 1: STG_LAUNCH_BWD(1); break;
-            case 2: STG_LAUNCH_BWD(2); break;
-            case 4: STG_LAUNCH_BWD(4); break;
-            default: STG_LAUNCH_BWD(8); break;
-        }
-    }
 #undef STG_LAUNCH_BWD
-    STG_LAUNCH_CHECK("stg_model_bwd: K1");
+        STG_LAUNCH_CHECK("stg_model_bwd: K1");
+    }
     evl.mark();
 
     ReduceArgs r{};
     r.slabs = scratch;
     r.grad = grad_params;
     r.n_params = L.n_params;
-    r.seg[r.n_seg++] = ReduceSeg{0, L.n_blk_params, slab_rows, n_small, 0};
+    r.seg[r.n_seg++] = ReduceSeg{0, L.n_blk_params, slab_rows, n_small, cv.rows};
     if (L.n_txp > 0) {
-        if (wave_path)
-            r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, STG_SKIP(a, 2) ? 0 : N, L.n_txp, (int64_t)(slopes - scratch)};
-        else
-            r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, slab_rows, n_small, (int64_t)L.n_blk_params};
+        r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, slab_rows, n_small, cv.rows + (int64_t)L.n_blk_params};
         WgradArgs w{};
         w.lay = L; w.num_peds = num_peds; w.order = a.tier.order; w.serpentine = a.tier.serpentine; w.N = N; w.V = V; w.dy = dy; w.ws = ws; w.dzg = dzg;
         w.ws_stride = a.ws_stride; w.slab2 = slab2; w.rows = wg.rows; w.debug_skip = a.debug_skip;
@@ -1296,12 +838,11 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
             STG_LAUNCH_CHECK("stg_model_bwd: K2");
         }
         evl.mark();
-        const int64_t s2 = slab2 - scratch;
         for (int l = 0; l <= L.L; ++l) {
             const int p0 = l == L.L ? L.out_w : L.txp_w[l];
             // (only the rows the layer's workgroups wrote: no memset of the slab needed)
             r.seg[r.n_seg++] = ReduceSeg{p0, wgrad_row_len(l), STG_SKIP(a, 1) ? 0 : wg.wg_begin[l + 1] - wg.wg_begin[l],
-                                         wgrad_row_len(l), s2 + wgrad_slab_base(l, wg.rows)};
+                                         wgrad_row_len(l), cv.slab2 + wgrad_slab_base(l, wg.rows)};
         }
     }
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((L.n_params + 7) / 8), dim3(256), 0, st, r);

@@ -66,8 +66,6 @@ __host__ __device__ inline int txp_sci(int vi) {
     const int raw = (Cfg::C + 4) * (vi + 2);
     return raw + ((16 - (raw & 31)) & 31);
 }
-// floats of the a_0 hand-off slot (block kernel -> TXP forward): T channels in the in-place layout
-__host__ __device__ inline int a0_slot(int V) { return Cfg::T * txp_sci(V); }
 // floats of one dz_l hand-off slot: position-major [C*V positions][P channels] (padded batch V)
 __host__ __device__ inline int dz_slot(int V) { return Cfg::P * Cfg::C * V; }
 
@@ -112,5 +110,11 @@ __host__ __device__ inline int64_t order_floats(int N, int V) { return ((int64_t
 // Fills order[0..N) with the scene indices sorted by clamp(num_peds[n], 0, V) descending (stable) on `st`;
 // returns false (order untouched) when the batch is outside the kernel's limits or num_peds is null.
 bool launch_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, int32_t *key_start, hipStream_t st);
+
+// stgcn_agg.hip: ax = x A ([cin][T][V_n]) and cs = colsum(A) ([T][V_n]) of every scene -- the one read of A in a
+// step -- written to out + n * out_stride + ax_off / cs_off.
+int launch_stgcn_agg(int cin, const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj,
+                     int64_t a_sn, const int32_t *num_peds, int N, int V, float *out, int64_t out_stride, int64_t ax_off,
+                     int64_t cs_off, hipStream_t st);
 
 }  // namespace stg

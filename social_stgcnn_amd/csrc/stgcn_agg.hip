@@ -1,0 +1,130 @@
+// stgcn_agg: the HBM-bound head of the first st_gcn block -- the adjacency-weighted aggregation of the CIN input
+// channels and the column sums of A that the re-associated 1x1 graph convolution needs (model.py:66-67):
+//     ax[n][ci][t][w] = sum_v x[n][ci][t][v] A[n][t][v][w]          cs[n][t][w] = sum_v A[n][t][v][w]
+// so that g = Wg ax + bg cs (2.5x fewer flops than conv-then-aggregate, and A is read exactly ONCE per step: the
+// backward works from the saved ax / cs).  This is the only kernel of the forward that touches A (32 V^2 bytes per
+// scene-window): a pure streaming kernel at full occupancy, so that the scene-resident kernels behind it start from
+// 96 V bytes per scene instead of paying A's HBM latency inside their dependent phases.
+//
+// One wave per scene-window (4 per workgroup).  x[n] (strided: the caller's permute(0,3,1,2) view) is staged in the
+// wave's LDS slice; lanes own (t, 4 consecutive w) strips when V is a multiple of 4 (16-byte loads along w, 8 rows in
+// flight per lane), single (t, w) columns otherwise (16 rows in flight).  Outputs are compact ([.][T][V_n]): the
+// layout of the saved arrays the block kernels index.
+#include "model_common.hpp"
+
+namespace stg {
+
+namespace {
+
+constexpr int T = Cfg::T;
+
+template <int CIN, int VEC>
+__global__ __launch_bounds__(256) void stgcn_agg_kernel(const float *__restrict__ x, int64_t x_sn, int64_t x_sc,
+                                                        int64_t x_st, int64_t x_sv, const float *__restrict__ adj,
+                                                        int64_t a_sn, const int32_t *__restrict__ num_peds, int N, int V,
+                                                        float *__restrict__ out, int64_t out_stride, int64_t ax_off,
+                                                        int64_t cs_off) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    int vi = num_peds ? num_peds[n] : V;
+    vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
+    if (vi == 0) return;
+    float *xs = sm + wave * (CIN * T * V);            // [CIN][T][vi]
+    const float *xn = x + n * x_sn;
+    for (int e = lane; e < CIN * T * vi; e += 64) {
+        const int v = e % vi, ct = e / vi, t = ct % T, c = ct / T;
+        xs[e] = xn[c * x_sc + t * x_st + v * x_sv];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float *an = adj + n * a_sn;
+    float *axo = out + n * out_stride + ax_off, *cso = out + n * out_stride + cs_off;
+    const int vq = (vi + VEC - 1) / VEC;
+    for (int q = lane; q < T * vq; q += 64) {
+        const int t = q / vq, w0 = (q - t * vq) * VEC;
+        float ax[CIN][VEC], cs[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            cs[j] = 0.f;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) ax[ci][j] = 0.f;
+        }
+        const float *at = an + (int64_t)t * V * V + w0;
+        const float *xt = xs + t * vi;
+        constexpr int U = VEC == 4 ? 8 : 16;          // rows in flight per lane
+        for (int v0 = 0; v0 < vi; v0 += U) {
+            float av[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (v0 + u < vi) {
+                    if (VEC == 4) {
+                        const float4 a4 = *reinterpret_cast<const float4 *>(at + (int64_t)(v0 + u) * V);
+                        av[u][0] = a4.x; av[u][1 % VEC] = a4.y; av[u][2 % VEC] = a4.z; av[u][3 % VEC] = a4.w;
+                    } else {
+                        av[u][0] = at[(int64_t)(v0 + u) * V];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) av[u][j] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (v0 + u < vi) {
+                    float xv[CIN];
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) xv[ci] = xt[ci * T * vi + v0 + u];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        cs[j] += av[u][j];
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) ax[ci][j] = fmaf(xv[ci], av[u][j], ax[ci][j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (w0 + j < vi) {
+                cso[t * vi + w0 + j] = cs[j];
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) axo[(ci * T + t) * vi + w0 + j] = ax[ci][j];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// out + n * out_stride + ax_off : ax [cin][T][V_n];  out + n * out_stride + cs_off : cs [T][V_n]
+int launch_stgcn_agg(int cin, const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj,
+                     int64_t a_sn, const int32_t *num_peds, int N, int V, float *out, int64_t out_stride, int64_t ax_off,
+                     int64_t cs_off, hipStream_t st) {
+    if (N == 0) return STG_OK;
+    const dim3 grid((N + 3) / 4), block(256);
+    const size_t lds = (size_t)4 * cin * T * V * sizeof(float);
+    STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stgcn_agg: V=%d needs %zu bytes of LDS", V, lds);
+    // 16-byte loads need 16-byte aligned rows: V a multiple of 4 and a 16-byte aligned base / batch stride
+    const bool vec = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(adj) & 15) == 0) && (a_sn % 4 == 0);
+#define STG_AGG(CI, VE)                                                                                          \
+    do {                                                                                                         \
+        if (lds > 64 * 1024) {                                                                                   \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&stgcn_agg_kernel<CI, VE>),       \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+            if (e_ != hipSuccess) return hip_fail(e_, "stgcn_agg: hipFuncSetAttribute");                        \
+        }                                                                                                        \
+        hipLaunchKernelGGL((stgcn_agg_kernel<CI, VE>), grid, block, lds, st, x, x_sn, x_sc, x_st, x_sv, adj, a_sn, \
+                           num_peds, N, V, out, out_stride, ax_off, cs_off);                                     \
+    } while (0)
+    if (cin == Cfg::CIN0) {
+        if (vec) STG_AGG(Cfg::CIN0, 4); else STG_AGG(Cfg::CIN0, 1);
+    } else {
+        if (vec) STG_AGG(Cfg::C, 4); else STG_AGG(Cfg::C, 1);
+    }
+#undef STG_AGG
+    STG_LAUNCH_CHECK("stgcn_agg");
+    return STG_OK;
+}
+
+}  // namespace stg

@@ -1,0 +1,768 @@
+// st_gcn block (model.py:92-155) forward and backward for ONE scene resident in LDS -- device code shared by the
+// workgroup-per-scene kernels (model_fwd.hip / model_bwd.hip: WAVES wave64 cooperate on a scene, __syncthreads
+// between phases) and the wave-per-scene kernels (txp_wave.hip: WAVES = 0, one wave owns the scene, no workgroup
+// barrier anywhere -- the other waves of the workgroup are busy with their own scenes).
+//
+// VALU work, 3 % of the model's flops: lanes own (t, w) columns; the einsum is re-associated to aggregate the CIN
+// input channels first (g = Wg (x A) + bg colsum(A)); BatchNorm statistics are PER SCENE (the reference trains with
+// N = 1, train.py:173-177) through DPP wave reductions (+ LDS across waves in workgroup mode).
+#pragma once
+#include "model_common.hpp"
+
+namespace stg {
+
+constexpr int kRedMax = 32;   // widest block reduction (values)
+
+// Cooperation scope of a scene: WAVES >= 1 waves of a workgroup, or (WAVES == 0) the calling wave alone.
+template <int WAVES>
+struct Scope {
+    static constexpr int NT = WAVES ? WAVES * 64 : 64;
+    static __device__ __forceinline__ int tid() { return WAVES ? (int)threadIdx.x : (int)(threadIdx.x & 63); }
+    static __device__ __forceinline__ void sync() {
+        if (WAVES) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();     // one wave: LDS operations complete in program order
+    }
+};
+
+// Sum K per-thread values over the scope; every thread holds the totals on return.
+template <int K, int WAVES>
+__device__ __forceinline__ void block_sum(float (&v)[K], float *red) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    if (WAVES > 1) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) red[wave * K + k] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) s += red[w * K + k];
+            v[k] = s;
+        }
+    }
+}
+
+// Sum K per-thread values over the scope; totals land in tot[0..K) (LDS), visible to every thread on return.
+template <int K, int WAVES>
+__device__ __forceinline__ void block_reduce(float (&v)[K], float *red, float *tot) {
+    static_assert(K <= kRedMax, "reduction too wide");
+    using S = Scope<WAVES>;
+    const int tid = S::tid();
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    if (WAVES == 0) {
+        S::sync();
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) tot[k] = v[k];
+        }
+        S::sync();
+        return;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) red[wave * K + k] = v[k];
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += S::NT) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < (WAVES ? WAVES : 1); ++w) s += red[w * K + k];
+        tot[k] = s;
+    }
+    __syncthreads();
+}
+
+// What the block code needs from its caller's argument block (FwdArgs / BwdArgs / TxpFwdArgs / TxpBwdArgs all carry
+// these members): lay, V, adj, a_sn, x, x_sn, x_sc, x_st, x_sv.
+
+// ------------------------------------------------------------------------------------------
+// forward.  X [CIN][T][vi] block input (LDS), G / H [C][T][vi] scratch (LDS).
+//   pre_ax / pre_cs : the aggregated input x A ([CIN][T][vi]) and colsum(A) ([T][vi]) of THIS scene computed by
+//                     stgcn_agg_kernel (block 0), or null -> the block streams A itself (stacked blocks, whose input
+//                     only exists in LDS) and saves both for the backward.
+//   workgroup mode  : on return the block output s is in H (same layout) and, when `to_txp`, also scattered into the
+//                     zero-bordered TXP plane `plane` (a region of its own).
+//   wave mode       : `plane` may overlap X / G / H: the outputs are formed in registers, the whole plane image
+//                     (plane_zero_f4 16-byte vectors from plane_base) is zeroed, then the outputs are scattered.
+// ------------------------------------------------------------------------------------------
+constexpr int kWaveMaxCols = 9;      // columns per lane in wave mode: ceil(T * 68 / 64)
+
+template <int CIN, int WAVES, typename Args>
+__device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__restrict__ P_, const float *__restrict__ B_,
+                                const BlockLayout &b, int n, int vi, const float *X, float *G, float *H, float *red,
+                                float *wsn, float *statn, const float *pre_ax, const float *pre_cs, bool to_txp,
+                                float *plane, int plane_sc, float *plane_base, int plane_zero_f4, float *yblock,
+                                bool save_s) {
+    constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT;
+    using S = Scope<WAVES>;
+    constexpr int NT = S::NT;
+    const int tid = S::tid(), V = a.V;
+    const int cnt = T * vi;
+    const bool train = a.lay.bn_mode == 1;
+    const float eps = a.lay.eps;
+    float *wsa = wsn ? wsn + a.lay.ws_hdr_floats : nullptr;    // saved arrays sit behind the header
+
+    // ---- P1: aggregation of the CIN input channels + 1x1 conv (model.py:66-67) ------------------
+    float s1[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) s1[c] = 0.f;
+    if (pre_ax) {
+        for (int q = tid; q < cnt; q += NT) {
+            const int t = q / vi, w = q - t * vi;
+            float ax[CIN];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) ax[ci] = pre_ax[(ci * T + t) * vi + w];
+            const float csum = pre_cs[q];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float g = P_[b.gcn_b + c] * csum;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) g = fmaf(P_[b.gcn_w + c * CIN + ci], ax[ci], g);
+                G[(c * T + t) * vi + w] = g;
+                if (wsn) wsa[(int64_t)b.ws_g * V + (c * T + t) * vi + w] = g;
+                s1[c] += g;
+            }
+        }
+    } else {
+        const float *an = a.adj + n * a.a_sn;
+        for (int q = tid; q < cnt; q += NT) {
+            const int t = q / vi, w = q - t * vi;
+            float ax[CIN];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) ax[ci] = 0.f;
+            float csum = 0.f;
+            const float *at = an + (int64_t)t * V * V + w;
+            const float *xt = X + t * vi;
+            // column w of A[n,t]: 16 row loads in flight per lane (the loop is HBM-latency-bound otherwise)
+            constexpr int UA = 16;
+            for (int v0 = 0; v0 < vi; v0 += UA) {
+                float av[UA];
+#pragma unroll
+                for (int u = 0; u < UA; ++u) av[u] = (v0 + u) < vi ? at[(int64_t)(v0 + u) * V] : 0.f;
+#pragma unroll
+                for (int u = 0; u < UA; ++u) {
+                    if (v0 + u < vi) {
+                        csum += av[u];
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) ax[ci] = fmaf(xt[ci * T * vi + v0 + u], av[u], ax[ci]);
+                    }
+                }
+            }
+            if (wsn) {
+                wsa[(int64_t)b.ws_cs * V + q] = csum;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) wsa[(int64_t)b.ws_ax * V + (ci * T + t) * vi + w] = ax[ci];
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float g = P_[b.gcn_b + c] * csum;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) g = fmaf(P_[b.gcn_w + c * CIN + ci], ax[ci], g);
+                G[(c * T + t) * vi + w] = g;
+                if (wsn) wsa[(int64_t)b.ws_g * V + (c * T + t) * vi + w] = g;
+                s1[c] += g;
+            }
+        }
+    }
+    // ---- BatchNorm tcn.0 statistics (model.py:114) ------------------------------------------------
+    float m1[C], r1[C];
+    if (train) {
+        block_sum<C, WAVES>(s1, red);
+        float s2[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { m1[c] = s1[c] / (float)cnt; s2[c] = 0.f; }
+        S::sync();   // G complete
+        for (int q = tid; q < cnt; q += NT) {
+            const int t = q / vi, w = q - t * vi;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float d = G[(c * T + t) * vi + w] - m1[c];
+                s2[c] = fmaf(d, d, s2[c]);
+            }
+        }
+        block_sum<C, WAVES>(s2, red);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            r1[c] = 1.0f / sqrtf(s2[c] / (float)cnt + eps);
+            if (statn && tid == 0) {
+                statn[b.stat + c] = m1[c];
+                statn[b.stat + C + c] = s2[c] / (float)(cnt - 1);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            m1[c] = B_[b.buf + c];
+            r1[c] = 1.0f / sqrtf(B_[b.buf + C + c] + eps);
+        }
+        S::sync();
+    }
+    if (wsn && tid == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            wsn[b.ws_hdr + c] = m1[c];
+            wsn[b.ws_hdr + C + c] = r1[c];
+        }
+    }
+    // ---- P3: BN + PReLU in place (tcn.0, tcn.1) --------------------------------------------------
+    {
+        const float al = P_[b.prelu1];
+        for (int q = tid; q < cnt; q += NT) {
+            const int t = q / vi, w = q - t * vi;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = (c * T + t) * vi + w;
+                const float v = fmaf((G[i] - m1[c]) * r1[c], P_[b.bn1_g + c], P_[b.bn1_b + c]);
+                G[i] = v > 0.f ? v : al * v;
+            }
+        }
+    }
+    S::sync();
+    // ---- P4: temporal conv (tcn.2) + residual 1x1 conv statistics -------------------------------
+    float s2r[2 * C];
+#pragma unroll
+    for (int c = 0; c < 2 * C; ++c) s2r[c] = 0.f;
+    for (int q = tid; q < cnt; q += NT) {
+        const int t = q / vi, w = q - t * vi;
+        float h[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) h[c] = P_[b.tcn_b + c];
+#pragma unroll
+        for (int dt = 0; dt < KT; ++dt) {
+            const int ti = t + dt - (KT - 1) / 2;
+            if (ti < 0 || ti >= T) continue;
+#pragma unroll
+            for (int ci = 0; ci < C; ++ci) {
+                const float hv = G[(ci * T + ti) * vi + w];
+#pragma unroll
+                for (int c = 0; c < C; ++c) h[c] = fmaf(P_[b.tcn_w + (c * C + ci) * KT + dt], hv, h[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            H[(c * T + t) * vi + w] = h[c];
+            if (wsn) wsa[(int64_t)b.ws_h2 * V + (c * T + t) * vi + w] = h[c];
+            s2r[c] += h[c];
+        }
+        if (b.residual == 2) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float r = P_[b.res_b + c];
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) r = fmaf(P_[b.res_w + c * CIN + ci], X[(ci * T + t) * vi + w], r);
+                s2r[C + c] += r;
+            }
+        }
+    }
+    float m2[C], r2[C], mr[C], rr[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { mr[c] = 0.f; rr[c] = 0.f; }
+    if (train) {
+        block_sum<2 * C, WAVES>(s2r, red);
+        float v2r[2 * C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            m2[c] = s2r[c] / (float)cnt;
+            mr[c] = s2r[C + c] / (float)cnt;
+            v2r[c] = 0.f;
+            v2r[C + c] = 0.f;
+        }
+        S::sync();   // H complete
+        for (int q = tid; q < cnt; q += NT) {
+            const int t = q / vi, w = q - t * vi;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float d = H[(c * T + t) * vi + w] - m2[c];
+                v2r[c] = fmaf(d, d, v2r[c]);
+            }
+            if (b.residual == 2) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float r = P_[b.res_b + c];
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci)
+                        r = fmaf(P_[b.res_w + c * CIN + ci], X[(ci * T + t) * vi + w], r);
+                    const float d = r - mr[c];
+                    v2r[C + c] = fmaf(d, d, v2r[C + c]);
+                }
+            }
+        }
+        block_sum<2 * C, WAVES>(v2r, red);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            r2[c] = 1.0f / sqrtf(v2r[c] / (float)cnt + eps);
+            rr[c] = 1.0f / sqrtf(v2r[C + c] / (float)cnt + eps);
+            if (statn && tid == 0) {
+                statn[b.stat + 2 * C + c] = m2[c];
+                statn[b.stat + 3 * C + c] = v2r[c] / (float)(cnt - 1);
+                if (b.residual == 2) {
+                    statn[b.stat + 4 * C + c] = mr[c];
+                    statn[b.stat + 5 * C + c] = v2r[C + c] / (float)(cnt - 1);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            m2[c] = B_[b.buf + 2 * C + c];
+            r2[c] = 1.0f / sqrtf(B_[b.buf + 3 * C + c] + eps);
+            if (b.residual == 2) {
+                mr[c] = B_[b.buf + 4 * C + c];
+                rr[c] = 1.0f / sqrtf(B_[b.buf + 5 * C + c] + eps);
+            }
+        }
+        S::sync();
+    }
+    if (wsn && tid == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            wsn[b.ws_hdr + 2 * C + c] = m2[c];
+            wsn[b.ws_hdr + 3 * C + c] = r2[c];
+            wsn[b.ws_hdr + 4 * C + c] = mr[c];
+            wsn[b.ws_hdr + 5 * C + c] = rr[c];
+        }
+    }
+    // ---- P6: BN (tcn.3) + residual + PReLU (model.py:150-153) ------------------------------------
+    const float ao = P_[b.prelu_o];
+    const int SW = txp_sw(vi), SC = plane_sc;
+    auto out_value = [&](int c, int t, int w) -> float {
+        const int i = (c * T + t) * vi + w;
+        float u = fmaf((H[i] - m2[c]) * r2[c], P_[b.bn2_g + c], P_[b.bn2_b + c]);
+        if (b.residual == 2) {
+            float r = P_[b.res_b + c];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) r = fmaf(P_[b.res_w + c * CIN + ci], X[(ci * T + t) * vi + w], r);
+            u += fmaf((r - mr[c]) * rr[c], P_[b.bnr_g + c], P_[b.bnr_b + c]);
+        } else if (b.residual == 1) {
+            if (CIN == C) u += X[i];
+        }
+        return (a.lay.use_mdn || u > 0.f) ? u : ao * u;
+    };
+    if (WAVES == 0) {
+        // wave mode: the plane image overlaps X / G / H.  Every lane forms the outputs of its columns in registers,
+        // then the wave zeroes the whole image and scatters them.
+        float sv[kWaveMaxCols][C];
+#pragma unroll
+        for (int k = 0; k < kWaveMaxCols; ++k) {
+            const int q = tid + 64 * k;
+            if (q < cnt) {
+                const int t = q / vi, w = q - t * vi;
+#pragma unroll
+                for (int c = 0; c < C; ++c) sv[k][c] = out_value(c, t, w);
+            }
+        }
+        S::sync();
+        if (to_txp) {
+            float4 *z4 = reinterpret_cast<float4 *>(plane_base);
+            for (int e = tid; e < plane_zero_f4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            S::sync();
+        }
+#pragma unroll
+        for (int k = 0; k < kWaveMaxCols; ++k) {
+            const int q = tid + 64 * k;
+            if (q < cnt) {
+                const int t = q / vi, w = q - t * vi;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float s = sv[k][c];
+                    if (wsn && save_s) wsa[(int64_t)b.ws_s * V + (c * T + t) * vi + w] = s;
+                    if (to_txp) {
+                        const int f = c * T + t, ch = f / C, row = f - ch * C;
+                        plane[ch * SC + (row + 1) * SW + (w + 1)] = s;
+                    } else {
+                        H[(c * T + t) * vi + w] = s;
+                    }
+                    if (yblock) yblock[(int64_t)(c * T + t) * V + w] = s;
+                }
+            }
+        }
+    } else {
+        for (int q = tid; q < cnt; q += NT) {
+            const int t = q / vi, w = q - t * vi;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = (c * T + t) * vi + w;
+                const float s = out_value(c, t, w);
+                H[i] = s;
+                if (wsn && save_s) wsa[(int64_t)b.ws_s * V + i] = s;
+                if (to_txp) {
+                    // v.view(N, T, C, V) (model.py:187): flat plane index f = c*T+t -> (f / C, f % C)
+                    const int f = c * T + t, ch = f / C, row = f - ch * C;
+                    plane[ch * SC + (row + 1) * SW + (w + 1)] = s;
+                }
+                if (yblock) yblock[(int64_t)(c * T + t) * V + w] = s;
+            }
+        }
+    }
+    S::sync();
+}
+
+// ------------------------------------------------------------------------------------------
+// backward.  ds (gradient w.r.t. the block output, [C][T][vi]) is in `D` (LDS) and is consumed in place.  If `dxs`
+// != nullptr the gradient w.r.t. the block input is written there ([CIN][T][vi], LDS; may alias D) -- needed for
+// stacked blocks; `dxg` is the optional global dx.  Small-parameter gradients go to `gsm`: ACCUM = true adds (an
+// LDS accumulator that lives for the whole launch), false stores (a per-scene row in HBM; every entry of the block's
+// parameters is written exactly once per scene).
+// ------------------------------------------------------------------------------------------
+template <int CIN, int WAVES, bool ACCUM, typename Args>
+__device__ __forceinline__ void stgcn_block_bwd(const Args &a, const float *P_, const BlockLayout &b, int n, int vi,
+                                float *D, float *H1,
+                                float *DH2, float *DB1, float *red, float *tot, float *gsm, const float *wsn,
+                                const float *xin_ws /* block input saved by the previous block, or null */,
+                                float *dxs, float *dxg, const float *lds_saved /* staged [ax|cs|g|h2] or null */) {
+    constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, TP = T + 2;
+    using S = Scope<WAVES>;
+    constexpr int NT = S::NT;
+    const int tid = S::tid(), V = a.V, cnt = T * vi;
+    const bool train = a.lay.bn_mode == 1;
+    const float inv_cnt = 1.0f / (float)cnt;
+    auto put = [&](int idx, float v) {
+        if (ACCUM) gsm[idx] += v;
+        else gsm[idx] = v;
+    };
+    const float *wsa = wsn + a.lay.ws_hdr_floats;     // saved arrays sit behind the header
+    const float *w_ax = wsa + (int64_t)b.ws_ax * V, *w_cs = wsa + (int64_t)b.ws_cs * V;
+    const float *w_g = wsa + (int64_t)b.ws_g * V, *w_h2 = wsa + (int64_t)b.ws_h2 * V;
+    if (lds_saved) {      // the kernel staged the four arrays into LDS with one DMA burst (compact, 4-float padded)
+        const int n_ax = (CIN * T * vi + 3) & ~3, n_cs = (T * vi + 3) & ~3, n_g = (C * T * vi + 3) & ~3;
+        w_ax = lds_saved;
+        w_cs = w_ax + n_ax;
+        w_g = w_cs + n_cs;
+        w_h2 = w_g + n_g;
+    }
+    const float *hdr = wsn + b.ws_hdr;
+    float m1[C], r1[C], m2[C], r2[C], mr[C], rr[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        m1[c] = hdr[c]; r1[c] = hdr[C + c]; m2[c] = hdr[2 * C + c];
+        r2[c] = hdr[3 * C + c]; mr[c] = hdr[4 * C + c]; rr[c] = hdr[5 * C + c];
+    }
+    const float *xn = a.x + n * a.x_sn;
+    auto load_x = [&](int ci, int t, int w) -> float {
+        return xin_ws ? xin_ws[(ci * T + t) * vi + w] : xn[ci * a.x_sc + t * a.x_st + w * a.x_sv];
+    };
+
+    // ---- B1: du = ds * prelu'(u); BatchNorm tcn.3 / residual.1 reductions; h1 = prelu(bn1(g)) ----
+    {
+        float s[3 * C + 1];
+#pragma unroll
+        for (int k = 0; k < 3 * C + 1; ++k) s[k] = 0.f;
+        const float ao = P_[b.prelu_o], a1 = P_[b.prelu1];
+        // loop-invariant parameters into registers once per pass (the compiler cannot hoist them itself:
+        // params may alias the kernel's stores)
+        float g2[C], b2[C], gr[C], br[C], g1[C], b1p[C], rb[C], rw[C * CIN];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            g2[c] = P_[b.bn2_g + c]; b2[c] = P_[b.bn2_b + c]; g1[c] = P_[b.bn1_g + c]; b1p[c] = P_[b.bn1_b + c];
+            gr[c] = b.residual == 2 ? P_[b.bnr_g + c] : 0.f;
+            br[c] = b.residual == 2 ? P_[b.bnr_b + c] : 0.f;
+            rb[c] = b.residual == 2 ? P_[b.res_b + c] : 0.f;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) rw[c * CIN + ci] = b.residual == 2 ? P_[b.res_w + c * CIN + ci] : 0.f;
+        }
+        // zero rows of the t-padded h1 plane
+        for (int e = tid; e < C * vi; e += NT) {
+            const int c = e / vi, w = e - c * vi;
+            H1[(c * TP) * vi + w] = 0.f;
+            H1[(c * TP + T + 1) * vi + w] = 0.f;
+        }
+        for (int q = tid; q < cnt; q += NT) {
+            const int t = q / vi, w = q - t * vi;
+            float xv[CIN];
+            if (b.residual != 0) {
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) xv[ci] = load_x(ci, t, w);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = (c * T + t) * vi + w;
+                const float x2 = (w_h2[i] - m2[c]) * r2[c];
+                float u = fmaf(x2, g2[c], b2[c]);
+                float xr = 0.f;
+                if (b.residual == 2) {
+                    float r = rb[c];
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) r = fmaf(rw[c * CIN + ci], xv[ci], r);
+                    xr = (r - mr[c]) * rr[c];
+                    u += fmaf(xr, gr[c], br[c]);
+                } else if (b.residual == 1) {
+                    if (CIN == C) u += xv[c % CIN];
+                }
+                const float ds = D[i];
+                float du = ds;
+                if (!a.lay.use_mdn && !(u > 0.f)) {
+                    du = ao * ds;
+                    s[3 * C] = fmaf(ds, u, s[3 * C]);
+                }
+                D[i] = du;
+                s[c] += du;
+                s[C + c] = fmaf(du, x2, s[C + c]);
+                s[2 * C + c] = fmaf(du, xr, s[2 * C + c]);
+                // h1 for the temporal-conv weight gradient
+                const float b1 = fmaf((w_g[i] - m1[c]) * r1[c], g1[c], b1p[c]);
+                H1[(c * TP + t + 1) * vi + w] = b1 > 0.f ? b1 : a1 * b1;
+            }
+        }
+        block_reduce<3 * C + 1, WAVES>(s, red, tot);
+        for (int k = tid; k < 3 * C + 1; k += NT) {
+            const float v = tot[k];
+            if (k < C) {
+                put(b.bn2_b + k, v);
+                if (b.residual == 2) put(b.bnr_b + k, v);
+            } else if (k < 2 * C) {
+                put(b.bn2_g + k - C, v);
+            } else if (k < 3 * C) {
+                if (b.residual == 2) put(b.bnr_g + k - 2 * C, v);
+            } else {
+                put(b.prelu_o, v);
+            }
+        }
+    }
+    float mdu[C], mdx2[C], mdxr[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        mdu[c] = train ? tot[c] * inv_cnt : 0.f;
+        mdx2[c] = train ? tot[C + c] * inv_cnt : 0.f;
+        mdxr[c] = train ? tot[2 * C + c] * inv_cnt : 0.f;
+    }
+    // ---- B2: dh2, dr; residual 1x1 conv gradients ------------------------------------------------
+    {
+        constexpr int K2 = C * CIN + C;
+        float s[K2];
+#pragma unroll
+        for (int k = 0; k < K2; ++k) s[k] = 0.f;
+        float g2[C], gr[C], rb[C], rw[C * CIN];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            g2[c] = P_[b.bn2_g + c];
+            gr[c] = b.residual == 2 ? P_[b.bnr_g + c] : 0.f;
+            rb[c] = b.residual == 2 ? P_[b.res_b + c] : 0.f;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) rw[c * CIN + ci] = b.residual == 2 ? P_[b.res_w + c * CIN + ci] : 0.f;
+        }
+        S::sync();       // (wave mode: the totals above were read from LDS before the next reduction overwrites them)
+        for (int q = tid; q < cnt; q += NT) {
+            const int t = q / vi, w = q - t * vi;
+            float xv[CIN];
+            if (b.residual == 2) {
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) xv[ci] = load_x(ci, t, w);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = (c * T + t) * vi + w;
+                const float du = D[i];
+                const float x2 = (w_h2[i] - m2[c]) * r2[c];
+                DH2[(c * TP + t + 1) * vi + w] = g2[c] * r2[c] * (du - mdu[c] - x2 * mdx2[c]);
+                if (b.residual == 2) {
+                    float r = rb[c];
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) r = fmaf(rw[c * CIN + ci], xv[ci], r);
+                    const float xr = (r - mr[c]) * rr[c];
+                    const float dr = gr[c] * rr[c] * (du - mdu[c] - xr * mdxr[c]);
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) s[c * CIN + ci] = fmaf(dr, xv[ci], s[c * CIN + ci]);
+                    s[C * CIN + c] += dr;
+                }
+            }
+        }
+        for (int e = tid; e < C * vi; e += NT) {
+            const int c = e / vi, w = e - c * vi;
+            DH2[(c * TP) * vi + w] = 0.f;
+            DH2[(c * TP + T + 1) * vi + w] = 0.f;
+        }
+        if (b.residual == 2) {
+            block_reduce<K2, WAVES>(s, red, tot);
+            for (int k = tid; k < K2; k += NT) {
+                if (k < C * CIN) put(b.res_w + k, tot[k]);
+                else put(b.res_b + k - C * CIN, tot[k]);
+            }
+        } else {
+            S::sync();
+        }
+    }
+    // ---- B3a: temporal conv weight gradients, one temporal tap at a time (25 accumulators, not 75) -------
+    for (int dt = 0; dt < KT; ++dt) {
+        float s[C * C];
+#pragma unroll
+        for (int k = 0; k < C * C; ++k) s[k] = 0.f;
+        for (int q = tid; q < cnt; q += NT) {
+            const int t = q / vi, w = q - t * vi;
+            float dh[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) dh[c] = DH2[(c * TP + t + 1) * vi + w];
+#pragma unroll
+            for (int ci = 0; ci < C; ++ci) {
+                // h1 at t + dt - 1 (t-padded plane, rows 0 and T+1 are zero)
+                const float hv = H1[(ci * TP + t + dt) * vi + w];
+#pragma unroll
+                for (int c = 0; c < C; ++c) s[c * C + ci] = fmaf(dh[c], hv, s[c * C + ci]);
+            }
+        }
+        block_reduce<C * C, WAVES>(s, red, tot);
+        for (int k = tid; k < C * C; k += NT) put(b.tcn_w + k * KT + dt, tot[k]);
+        if (WAVES == 0) S::sync();
+    }
+    // ---- B3b: dh1 -> db1, conv bias gradient, BatchNorm tcn.0 reductions, PReLU slope ---------------------
+    {
+        constexpr int K3 = 3 * C + 1;                  // conv bias, sum db1, sum db1*xhat1, prelu slope
+        float s[K3];
+#pragma unroll
+        for (int k = 0; k < K3; ++k) s[k] = 0.f;
+        const float a1 = P_[b.prelu1];
+        float tw[C * C * KT], g1[C], b1p[C];
+#pragma unroll
+        for (int k = 0; k < C * C * KT; ++k) tw[k] = P_[b.tcn_w + k];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { g1[c] = P_[b.bn1_g + c]; b1p[c] = P_[b.bn1_b + c]; }
+        for (int q = tid; q < cnt; q += NT) {
+            const int t = q / vi, w = q - t * vi;
+            float dh1[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                s[c] += DH2[(c * TP + t + 1) * vi + w];
+                dh1[c] = 0.f;
+            }
+            // input gradient: dh1[ci][t] = sum_{c,dt} Wt[c][ci][dt] dh2[c][t - dt + 1]
+#pragma unroll
+            for (int dt = 0; dt < KT; ++dt)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float dv = DH2[(c * TP + t - dt + 2) * vi + w];
+#pragma unroll
+                    for (int ci = 0; ci < C; ++ci) dh1[ci] = fmaf(tw[(c * C + ci) * KT + dt], dv, dh1[ci]);
+                }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = (c * T + t) * vi + w;
+                const float x1 = (w_g[i] - m1[c]) * r1[c];
+                const float b1 = fmaf(x1, g1[c], b1p[c]);
+                float db = dh1[c];
+                if (!(b1 > 0.f)) {
+                    db = a1 * dh1[c];
+                    s[3 * C] = fmaf(dh1[c], b1, s[3 * C]);
+                }
+                DB1[i] = db;
+                s[C + c] += db;
+                s[2 * C + c] = fmaf(db, x1, s[2 * C + c]);
+            }
+        }
+        block_reduce<K3, WAVES>(s, red, tot);
+        for (int k = tid; k < K3; k += NT) {
+            const float v = tot[k];
+            if (k < C) put(b.tcn_b + k, v);
+            else if (k < 2 * C) put(b.bn1_b + k - C, v);
+            else if (k < 3 * C) put(b.bn1_g + k - 2 * C, v);
+            else put(b.prelu1, v);
+        }
+    }
+    float mdb[C], mdbx[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        mdb[c] = train ? tot[C + c] * inv_cnt : 0.f;
+        mdbx[c] = train ? tot[2 * C + c] * inv_cnt : 0.f;
+    }
+    // ---- B4: dg; gcn 1x1 conv gradients; d(aggregated input) -------------------------------------
+    {
+        constexpr int K4 = C * CIN + C;
+        float s[K4];
+#pragma unroll
+        for (int k = 0; k < K4; ++k) s[k] = 0.f;
+        const bool want_dx = dxs != nullptr || dxg != nullptr;
+        float g1[C], gw[C * CIN];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            g1[c] = P_[b.bn1_g + c];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) gw[c * CIN + ci] = P_[b.gcn_w + c * CIN + ci];
+        }
+        S::sync();       // (wave mode: mdb / mdbx were read from LDS before the next reduction overwrites them)
+        for (int q = tid; q < cnt; q += NT) {
+            const int t = q / vi, w = q - t * vi;
+            float axv[CIN], dax[CIN];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                axv[ci] = w_ax[(ci * T + t) * vi + w];
+                dax[ci] = 0.f;
+            }
+            const float csum = w_cs[q];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = (c * T + t) * vi + w;
+                const float x1 = (w_g[i] - m1[c]) * r1[c];
+                const float dg = g1[c] * r1[c] * (DB1[i] - mdb[c] - x1 * mdbx[c]);
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    s[c * CIN + ci] = fmaf(dg, axv[ci], s[c * CIN + ci]);
+                    dax[ci] = fmaf(gw[c * CIN + ci], dg, dax[ci]);
+                }
+                s[C * CIN + c] = fmaf(dg, csum, s[C * CIN + c]);
+            }
+            if (want_dx) {
+                // stash d(ax) in the (now free) h1 plane: [CIN][T][vi]
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) H1[(ci * T + t) * vi + w] = dax[ci];
+            }
+        }
+        block_reduce<K4, WAVES>(s, red, tot);
+        for (int k = tid; k < K4; k += NT) {
+            if (k < C * CIN) put(b.gcn_w + k, tot[k]);
+            else put(b.gcn_b + k - C * CIN, tot[k]);
+        }
+        if (want_dx) {
+            // ---- B5: dx[ci][t][v] = sum_w dax[ci][t][w] A[t][v][w] + residual path -----------------
+            const float *an = a.adj + n * a.a_sn;
+            for (int q = tid; q < cnt; q += NT) {
+                const int t = q / vi, v = q - t * vi;
+                float acc[CIN];
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.f;
+                const float *arow = an + ((int64_t)t * V + v) * V;
+                for (int w = 0; w < vi; ++w) {
+                    const float av = arow[w];
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) acc[ci] = fmaf(H1[(ci * T + t) * vi + w], av, acc[ci]);
+                }
+                if (b.residual == 2) {
+                    float xv[CIN];
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) xv[ci] = load_x(ci, t, v);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const int i = (c * T + t) * vi + v;
+                        float r = P_[b.res_b + c];
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) r = fmaf(P_[b.res_w + c * CIN + ci], xv[ci], r);
+                        const float xr = (r - mr[c]) * rr[c];
+                        const float dr = P_[b.bnr_g + c] * rr[c] * (D[i] - mdu[c] - xr * mdxr[c]);
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) acc[ci] = fmaf(P_[b.res_w + c * CIN + ci], dr, acc[ci]);
+                    }
+                } else if (b.residual == 1) {
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci)
+                        if (CIN == C) acc[ci] += D[(ci * T + t) * vi + v];
+                }
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    if (dxg) dxg[(int64_t)(ci * T + t) * V + v] = acc[ci];
+                    if (dxs) DB1[(ci * T + t) * vi + v] = acc[ci];      // staged; copied to D after the barrier
+                }
+            }
+            S::sync();
+            if (dxs)
+                for (int e = tid; e < CIN * cnt; e += NT) dxs[e] = DB1[e];
+            S::sync();
+        }
+    }
+}
+
+}  // namespace stg

@@ -14,6 +14,7 @@
 // prefetched while the current layer computes).  Epilogues write position-major [pos][12] images with
 // 16-byte stores: the layout the weight-gradient GEMM (model_bwd.hip, K2) stages back with LDS-DMA.
 #include "model_common.hpp"
+#include "stgcn_block.hpp"
 #include "txp_wave.hpp"
 
 namespace stg {
@@ -21,6 +22,12 @@ namespace stg {
 namespace {
 
 constexpr int C = Cfg::C, P = Cfg::P, T = Cfg::T;
+
+// the backward's position table doubles as the st_gcn tail's 32 reduction totals
+__host__ __device__ inline int bwd_ptab_floats(int v) {
+    const int t = (C * v + 3) & ~3;
+    return t > kRedMax ? t : kRedMax;
+}
 
 // A lane's weights of one (co, ci) pair are 9 consecutive floats (the taps): two 16-byte loads + one dword per pair
 // instead of nine scattered dwords (every lane reads a different cache line, so the request count is what costs)
@@ -255,36 +262,71 @@ __device__ __forceinline__ void zero_row_slot(float *buf, int slot_row, int SW, 
         for (int c = lane; c < SW; c += 64) row[ch * SC + c] = 0.f;
 }
 
-__device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float *buf, unsigned *ptab) {
+// One scene-window, whole model.  `buf` = the wave's LDS region: the in-place TXP plane image [P][txp_sci(vi)], which
+// during the st_gcn block phase holds the block's arrays instead -- G [C][T][vi] at the start, the block input X
+// [CIN0][T][vi] behind it, H [C][T][vi] at the END of the image (96 vi <= P txp_sci(vi) - 40 vi always).  The block
+// forms its outputs in registers, zeroes the image and scatters a_0 into it (stgcn_block_fwd, wave mode): the block
+// output never visits HBM on its way to the TXP-CNN.
+__device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, const float *__restrict__ params,
+                                              const float *__restrict__ buffers, int n, float *buf, unsigned *ptab) {
     const ModelLayout &L = a.lay;
     const int V = a.V, lane = threadIdx.x & 63;
     STG_STAMP(0);
     int vi = a.num_peds ? a.num_peds[n] : V;
     vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
-    if (vi == 0) return;                               // (the block kernel already zero-filled y)
-    const int SW = txp_sw(vi), SC = txp_sci(vi);
-    const float *Pm = a.params;
     float *yn = a.y + (int64_t)n * (C * P) * V;
+    if (vi < V)                                        // padded pedestrian slots of the output are zeros
+        for (int e = lane; e < C * P * (V - vi); e += 64) {
+            const int r = e / (V - vi), w = vi + (e - r * (V - vi));
+            yn[(int64_t)r * V + w] = 0.f;
+        }
+    if (vi == 0) return;
+    const int SW = txp_sw(vi), SC = txp_sci(vi);
+    const float *Pm = params;
     float *wsn = a.ws ? a.ws + n * a.ws_stride : nullptr;
+    float *statn = a.stats ? a.stats + (int64_t)n * L.stat_floats : nullptr;
 
-    // a_0: T channels arrive in the in-place layout (rows at slot offset 2, zeros elsewhere); channels T..P-1 start
-    // as zeros (their borders must read 0 once layer 0 has written their interiors)
-    wave_dma(a.a0g + (int64_t)n * a0_slot(V), buf, (T * SC) >> 2);
-    wave_zero(buf + T * SC, ((P - T) * SC) >> 2);
-    build_ptab(ptab, vi, C * vi);
+    // ---- st_gcn block (model.py:145-155) ------------------------------------------------------------
+    {
+        float *G = buf, *X = buf + C * T * vi, *H = buf + P * SC - C * T * vi;
+        const float *xn = a.x + n * a.x_sn;
+        for (int e = lane; e < Cfg::CIN0 * T * vi; e += 64) {      // strided: the caller's permute(0,3,1,2) view
+            const int v = e % vi, ct = e / vi, t = ct % T, c = ct / T;
+            X[e] = xn[c * a.x_sc + t * a.x_st + v * a.x_sv];
+        }
+        build_ptab(ptab, vi, C * vi);
+        __builtin_amdgcn_wave_barrier();
+        const float *agn = a.agg + n * a.agg_stride;
+        stgcn_block_fwd<Cfg::CIN0, 0>(a, params, buffers, L.blk[0], n, vi, X, G, H, nullptr, wsn, statn, agn + a.agg_ax,
+                                      agn + a.agg_cs, true, buf + 2 * SW, SC, buf, (P * SC) >> 2, nullptr, false);
+    }
+    STG_STAMP(1);
+    // a_0 now sits in the in-place layout (T channels, rows at slot offset 2, zeros elsewhere)
     float w0[T * 9 / 4];
     load_w_fwd<T>(Pm + L.txp_w[0], w0);
-    // (while the DMA is in flight) training: the saved planes a_1 .. a_L hold the C interior rows WITH their two border
-    // columns ([C*SW][P], what the weight-gradient GEMM stages with one linear LDS-DMA): the borders are zeros
-    if (wsn && lane < 2 * C * 3) {
-        const int b = lane / 3, q = lane - b * 3, pos = (b >> 1) * SW + ((b & 1) ? SW - 1 : 0);
-        for (int l = 0; l < L.L; ++l)
-            *reinterpret_cast<float4 *>(wsn + ws_plane_off(L, V, l + 1) + pos * P + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wsn) {
+        // training: a_0 is saved position-major for the weight-gradient GEMM -- the C interior ROWS with their two
+        // border columns, [C*SW][P] (16-byte stores); the saved planes a_1 .. a_L get their zero border columns here
+        float *d2 = wsn + ws_plane_off(L, V, 0);
+        for (int h = 0; h < C; ++h)
+            for (int e = lane; e < SW * 3; e += 64) {              // (position, channel quad)
+                const int col = e / 3, q = e - col * 3;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < T / 4) {
+                    const float *src = buf + (4 * q) * SC + (h + 3) * SW + col;
+                    v = make_float4(src[0], src[SC], src[2 * SC], src[3 * SC]);
+                }
+                *reinterpret_cast<float4 *>(d2 + ((h * SW + col) * P + 4 * q)) = v;
+            }
+        if (lane < 2 * C * 3) {
+            const int b = lane / 3, q = lane - b * 3, pos = (b >> 1) * SW + ((b & 1) ? SW - 1 : 0);
+            for (int l = 0; l < L.L; ++l)
+                *reinterpret_cast<float4 *>(wsn + ws_plane_off(L, V, l + 1) + pos * P + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    STG_STAMP(1);
 
+    // ---- TXP-CNN (model.py:187-195) -------------------------------------------------------------------
     float *hi = buf + 2 * SW, *lo = buf;            // padded row 0 of the two positions of the plane
     float wa[27], wb[27];          // two weight register sets: layer l computes from one while l+1 loads
     auto w_of = [&](int l) { return Pm + (l < L.L ? L.txp_w[l] : L.out_w); };
@@ -331,11 +373,13 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, int n, float 
     else
         fwd_layer<P, 2, false>(wb, Pm + L.out_b, 0.f, (l & 1) ? lo : hi, nullptr, ptab, vi, V, nullptr, nullptr, yn);
     STG_STAMP(8);
-    (void)lane;
 }
 
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_fwd_wave_kernel(const TxpFwdArgs a) {
+__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_fwd_wave_kernel(
+    const TxpFwdArgs a, const float *__restrict__ params, const float *__restrict__ buffers) {
+    // params / buffers are separate __restrict__ kernel arguments on purpose: only then can the compiler prove that
+    // the kernel's own stores never clobber them and fetch the (wave-uniform) st_gcn weights with scalar loads
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Vl = a.Vl, wave = threadIdx.x >> 6;
     const int slot = P * txp_sci(Vl);
@@ -350,7 +394,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
         const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
-        txp_fwd_scene(a, n, pa, ptab);
+        txp_fwd_scene(a, params, buffers, n, pa, ptab);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -375,14 +419,38 @@ __device__ __forceinline__ void dgrad_layer(const float (&wreg)[27], const float
     (void)npos;
 }
 
+// Tail of the per-scene backward: the st_gcn block (model.py:145-155 backwards) in wave mode.  The input-gradient
+// chain left d(a_0) position-major in `dcur` ([pos][P], channels 0..T-1); the dz plane is dead, so the block's three
+// LDS arrays are carved from the start of the wave's region: D = d(block output) [C][T][vi] | h1 [C][T+2][vi] | dh2
+// [C][T+2][vi] (140 vi floats <= plane_slot + 60 V); db1 reuses D.  Small-parameter gradients leave as the scene's own
+// row (stores, no atomics): reduce_slabs_kernel sums the rows in a fixed order.
+__device__ __forceinline__ void txp_bwd_block_tail(const TxpBwdArgs &a, int n, int vi, float *dzb, float *dcur,
+                                                   unsigned *ptab, float *slope_row) {
+    const ModelLayout &L = a.lay;
+    const int lane = threadIdx.x & 63;
+    for (int e = L.L + lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;       // dead slopes (layers >= L)
+    if (STG_SKIP(a, 4)) return;
+    float *D = dzb, *H1 = dzb + C * T * vi, *DH2 = H1 + C * (T + 2) * vi;
+    float *tot = reinterpret_cast<float *>(ptab);          // (the position table is dead too: 32 floats of totals)
+    // v.view(N, T, C, V) (model.py:187) backwards: plane (ch, row) is flat f = ch*C + row = c*T + t of the block output
+    for (int f = 0; f < C * T; ++f) {
+        const int ch = f / C, row = f - ch * C;
+        for (int w = lane; w < vi; w += 64) D[f * vi + w] = dcur[(row * vi + w) * P + ch];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float *row = slope_row - L.n_blk_params;
+    stgcn_block_bwd<Cfg::CIN0, 0, false>(a, a.params, L.blk[0], n, vi, D, H1, DH2, D, nullptr, tot, row,
+                                         a.ws + n * a.ws_stride, nullptr, nullptr, nullptr, nullptr);
+}
+
 __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float *dzb, float *dcur, unsigned *ptab) {
     const ModelLayout &L = a.lay;
     const int V = a.V, lane = threadIdx.x & 63;
     int vi = a.num_peds ? a.num_peds[n] : V;
     vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
-    float *slope_row = a.slopes + (int64_t)n * L.n_txp;
-    if (vi == 0) {
-        for (int e = lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;
+    float *slope_row = a.rows + (int64_t)n * (L.n_blk_params + L.n_txp) + L.n_blk_params;
+    if (vi == 0) {                                     // empty scene: its row of small-parameter gradients is zero
+        for (int e = lane; e < L.n_blk_params + L.n_txp; e += 64) slope_row[e - L.n_blk_params] = 0.f;
         return;
     }
     const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi;
@@ -483,11 +551,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
         }
         __builtin_amdgcn_wave_barrier();
     }
-    // dead slopes (layers >= L) and the hand-off of d(a_0) = d(block output) [C][T][vi] to the st_gcn backward
-    for (int e = L.L + lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;
-    float *dout = a.da0 + (int64_t)n * (C * T * V);
-    for (int ch = 0; ch < T; ++ch)                       // [pos][P] in LDS -> [T][C*vi] (= [C][T][vi] flat) in HBM
-        for (int pos = lane; pos < npos; pos += 64) dout[ch * npos + pos] = dcur[pos * P + ch];
+    txp_bwd_block_tail(a, n, vi, dzb, dcur, ptab, slope_row);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -581,9 +645,9 @@ __device__ __forceinline__ void txp_bwd_scene_bf16(const TxpBwdArgs &a, int n, f
     const int V = a.V, lane = threadIdx.x & 63;
     int vi = a.num_peds ? a.num_peds[n] : V;
     vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
-    float *slope_row = a.slopes + (int64_t)n * L.n_txp;
-    if (vi == 0) {
-        for (int e = lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;
+    float *slope_row = a.rows + (int64_t)n * (L.n_blk_params + L.n_txp) + L.n_blk_params;
+    if (vi == 0) {                                     // empty scene: its row of small-parameter gradients is zero
+        for (int e = lane; e < L.n_blk_params + L.n_txp; e += 64) slope_row[e - L.n_blk_params] = 0.f;
         return;
     }
     const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi, npad = (C + 2) * SW;
@@ -686,10 +750,7 @@ __device__ __forceinline__ void txp_bwd_scene_bf16(const TxpBwdArgs &a, int n, f
         }
         __builtin_amdgcn_wave_barrier();
     }
-    for (int e = L.L + lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;
-    float *dout = a.da0 + (int64_t)n * (C * T * V);
-    for (int ch = 0; ch < T; ++ch)
-        for (int pos = lane; pos < npos; pos += 64) dout[ch * npos + pos] = dcur[pos * P + ch];
+    txp_bwd_block_tail(a, n, vi, dzb, dcur, ptab, slope_row);
 }
 
 template <int WPB, bool BF16>
@@ -697,7 +758,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) void txp_bwd_wave_kerne
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Vl = a.Vl, wave = threadIdx.x >> 6;
     const int slot = plane_slot(Vl);
-    const int per_wave = slot + P * C * Vl + ((C * Vl + 3) & ~3);
+    const int per_wave = slot + P * C * Vl + bwd_ptab_floats(Vl);
     float *dzb = sm + wave * per_wave, *dcur = dzb + slot;
     unsigned *ptab = reinterpret_cast<unsigned *>(dcur + P * C * Vl);
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;
@@ -772,7 +833,8 @@ __device__ __forceinline__ MixSlot mix_assign(const SceneTier &t, const MixGeom 
     return m;
 }
 
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_fwd_wave_mixed_kernel(const TxpFwdArgs a) {
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_fwd_wave_mixed_kernel(
+    const TxpFwdArgs a, const float *__restrict__ params, const float *__restrict__ buffers) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const MixSlot m = mix_assign(a.tier, a.mix, a.N, a.V);
     if (!m.active) return;
@@ -785,7 +847,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int it = walk_item(r, m.worker, m.nworkers, M, a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order[m.begin + it]);
-        txp_fwd_scene(a, n, pa, ptab);
+        txp_fwd_scene(a, params, buffers, n, pa, ptab);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -839,14 +901,14 @@ static int wave_grid(size_t lds, int wpb, int N) {
 }
 
 bool txp_wave_fits(const ModelLayout &L, int V) {
-    if (L.n_txp < 1 || L.n_blocks != 1) return false;
+    if (L.n_txp < 1 || L.n_blocks != 1 || L.blk[0].cin != Cfg::CIN0) return false;
     if (L.flags & STG_OPT_WG_PATH) return false;
     const size_t fwd = (size_t)2 * plane_slot(V) * sizeof(float);
     return fwd <= 48 * 1024;        // at least three waves per CU
 }
 
 static size_t fwd_per_wave_floats(int v) { return (size_t)P * txp_sci(v) + ((C * v + 3) & ~3); }
-static size_t bwd_per_wave_floats(int v) { return (size_t)plane_slot(v) + (size_t)P * C * v + ((C * v + 3) & ~3); }
+static size_t bwd_per_wave_floats(int v) { return (size_t)plane_slot(v) + (size_t)P * C * v + bwd_ptab_floats(v); }
 constexpr int kMixSmallV = 32;
 
 // geometry of the mixed-V launch for per-wave footprint `pw(v)`; false when the padded V does not call for it
@@ -879,7 +941,7 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_fwd_wave_mixed_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e_ != hipSuccess) return hip_fail(e_, "txp_fwd_wave_mixed: hipFuncSetAttribute");
-        hipLaunchKernelGGL(txp_fwd_wave_mixed_kernel, dim3(mix_grid(lds, a.N)), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(txp_fwd_wave_mixed_kernel, dim3(mix_grid(lds, a.N)), dim3(256), lds, st, a, a.params, a.buffers);
         STG_LAUNCH_CHECK("txp_fwd_wave_mixed");
         return STG_OK;
     }
@@ -892,7 +954,7 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_fwd_wave_kernel<W>),          \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
         if (e_ != hipSuccess) return hip_fail(e_, "txp_fwd_wave: hipFuncSetAttribute");                       \
-        hipLaunchKernelGGL(txp_fwd_wave_kernel<W>, grid, dim3(W * 64), lds, st, a);                           \
+        hipLaunchKernelGGL(txp_fwd_wave_kernel<W>, grid, dim3(W * 64), lds, st, a, a.params, a.buffers);       \
     } while (0)
     if (wpb == 8) STG_L(8); else if (wpb == 4) STG_L(4); else if (wpb == 2) STG_L(2); else STG_L(1);
 #undef STG_L
@@ -915,7 +977,7 @@ int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {
         STG_LAUNCH_CHECK("txp_bwd_wave_mixed");
         return STG_OK;
     }
-    const size_t per_wave = ((size_t)plane_slot(a.Vl) + (size_t)P * C * a.Vl + ((C * a.Vl + 3) & ~3)) * sizeof(float);
+    const size_t per_wave = bwd_per_wave_floats(a.Vl) * sizeof(float);
     const int wpb = wave_wpb(per_wave);
     const size_t lds = per_wave * wpb;
     const dim3 grid(wave_grid(lds, wpb, a.N));

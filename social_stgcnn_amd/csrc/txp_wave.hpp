@@ -15,21 +15,30 @@ struct MixGeom {
     int block_floats;     // LDS floats of one workgroup = 4 * per-wave floats at v_small
 };
 
+// forward: the WHOLE model per scene -- st_gcn block (from the aggregated input stgcn_agg_kernel left) + TXP-CNN
 struct TxpFwdArgs {
     ModelLayout lay;
-    const float *params;
+    const float *params, *buffers;
     const int32_t *num_peds;
     SceneTier tier;        // which scenes this launch serves (ragged batches: sorted, walked boustrophedon)
     int Vl;                // LDS geometry of the launch: >= every V_n of the tier (<= V)
     MixGeom mix;
     int N, V;
-    const float *a0g;      // [N][plane_slot(V)] channel-major zero-bordered a_0 planes from the block kernel
+    const float *x;        // (N, c_in, T, V) strided block input (residual branch)
+    int64_t x_sn, x_sc, x_st, x_sv;
+    const float *adj;      // (unused by the wave kernels: A was consumed by stgcn_agg_kernel)
+    int64_t a_sn;
+    const float *agg;      // per scene [agg_stride]: ax at agg_ax ([c_in][T][V_n]), cs at agg_cs ([T][V_n])
+    int64_t agg_stride, agg_ax, agg_cs;
     float *y;              // (N, C, P, V)
     float *ws;             // per-scene workspace or null (inference)
     int64_t ws_stride;
+    float *stats;          // (N, stat_floats) per-scene BatchNorm statistics (bn_mode 1) or null
     unsigned long long *stamps;   // diagnostic build only (STG_STAMPS=1): [N][16] s_memtime stamps, else null
+    int debug_skip;        // diagnostic builds only
 };
 
+// backward: TXP-CNN input-gradient chain + the st_gcn block backward per scene (everything but the TXP weight gradients)
 struct TxpBwdArgs {
     ModelLayout lay;
     const float *params;
@@ -38,12 +47,15 @@ struct TxpBwdArgs {
     int Vl;                // LDS geometry of the launch: >= every V_n of the tier (<= V)
     MixGeom mix;
     int N, V;
+    const float *x;        // (N, c_in, T, V) strided block input (residual branch)
+    int64_t x_sn, x_sc, x_st, x_sv;
+    const float *adj;      // (unused: no dx on this path, A is not needed)
+    int64_t a_sn;
     const float *dy;       // (N, C, P, V)
     const float *ws;
     int64_t ws_stride;
     float *dzg;            // [N][L][dz_slot(V)]   dz_l of the hidden layers for the weight-gradient GEMM
-    float *da0;            // [N][C*T*V]           gradient w.r.t. the st_gcn block output
-    float *slopes;         // [N][n_txp]           per-scene PReLU slope gradients
+    float *rows;           // [N][n_blk_params + n_txp]  per-scene small-parameter gradients: st_gcn block, PReLU slopes
     int debug_skip;        // timing-only diagnostic (STG_DEBUG_SKIP): 512 dz build, 1024 dgrad tile loops -- wrong results
     int split_bf16;        // 1: the input-gradient GEMMs run on bf16 MFMAs with hi/lo-split operands (see txp_wave.hip)
 };

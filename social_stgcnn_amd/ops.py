@@ -221,13 +221,14 @@ class KernelTimer:
 
 TIMER = None
 LAST_FWD_SCRATCH = None
+LAST_WS_FLOATS = 0            # diagnostics: activation workspace the last fused forward allocated (0 = inference)
 
 
 class _FusedModel(torch.autograd.Function):
     """x (N,Cin,T,V), adj -> y.  Extra (non-differentiable) arguments carry the packed buffers."""
 
     @staticmethod
-    def forward(ctx, x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, holder, *params):
+    def forward(ctx, x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, holder, grad_on, *params):
         require_gpu(x, adj, flat_params, flat_buffers)
         _lib.as_f32(x, "x")
         _lib.as_f32(adj, "adj")
@@ -239,16 +240,25 @@ class _FusedModel(torch.autograd.Function):
         adj_c, a_sn = _adj_layout(adj, n, t, v)
         peds = peds_arg(num_peds, n, x.device)
         training = desc.bn_mode == 1
-        # (needs_input_grad reflects requires_grad, not the grad mode: under no_grad nothing is saved)
-        need_grad = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        # needs_input_grad reflects requires_grad, not the grad mode (and forward() itself always runs with grad
+        # disabled): the caller's grad mode comes in as `grad_on`, so that under no_grad nothing is saved
+        need_grad = grad_on and any(ctx.needs_input_grad)
+        if need_grad and ctx.needs_input_grad[0] and not (desc.flags & _lib.OPT_WG_PATH):
+            # an input gradient is only computed by the workgroup-per-scene kernels (both passes must agree)
+            fields = {f: getattr(desc, f) for f, _ in ModelDesc._fields_}
+            fields["flags"] |= _lib.OPT_WG_PATH
+            desc = ModelDesc(**fields)
         out_t = desc.t_pred if desc.n_txpcnn > 0 else desc.t_obs
         y = torch.empty((n, desc.c_out, out_t, v), device=x.device, dtype=torch.float32)
+        global LAST_WS_FLOATS
+        LAST_WS_FLOATS = 0
         ws = None
         if need_grad:
             wsf = L.stg_model_ws_floats(ctypes.byref(desc), v)
             if wsf < 0:
                 check(int(wsf), "stg_model_ws_floats")
             ws = torch.empty(n * wsf, device=x.device, dtype=torch.float32)
+            LAST_WS_FLOATS = ws.numel()
         stats = None
         if training:
             sf = L.stg_model_stat_floats(ctypes.byref(desc))
@@ -314,11 +324,12 @@ class _FusedModel(torch.autograd.Function):
             off += cnt
         if ctx.holder is not None:
             ctx.holder._flat_grad = grad       # the trainer all-reduces / applies this buffer directly
-        return (dx, None, None, None, None, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, None, None, None, None, *grads)
 
 
 def fused_model(x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, params, holder=None):
-    return _FusedModel.apply(x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, holder, *params)
+    return _FusedModel.apply(x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, holder,
+                             torch.is_grad_enabled(), *params)
 
 
 # --------------------------------------------------------------------------------------------

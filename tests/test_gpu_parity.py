@@ -535,11 +535,27 @@ def test_large_v_and_workgroup_path(dev, v, force_generic, monkeypatch):
                         lambda name: None if params[name].grad is None else params[name].grad.numpy())
     print("V=%d%s: worst relative gradient error %.1e" % (v, " (workgroup path)" if force_generic else "",
                                                           max(errs.values())))
-    bad = {k: e for k, e in errs.items() if e > 2e-4}
+    bad = {k: e for k, e in errs.items() if e > 5e-5}           # measured worst case 3.4e-6 (V = 128)
     assert not bad, bad
     for k, val in m.state_dict().items():
         if "running" in k:
             assert _maxdiff(val.cpu().numpy(), work[k].numpy()) < 2e-6, k
+
+
+def test_no_grad_forward_saves_no_activations(dev):
+    """A forward under torch.no_grad() (vald(), test()) must run in inference mode -- no activation workspace, no
+    saved planes -- even though the parameters require grad; with grad enabled the workspace is there."""
+    from social_stgcnn_amd import ops
+    m = _model(dev, seed=1).train()
+    rel = torch.from_numpy(np.stack([_synthetic_scene(9, 5), _synthetic_scene(9, 6)])).to(dev)
+    nodes, adj = ops.adj_build(rel[..., :8])
+    x = nodes.permute(0, 3, 1, 2)
+    y1, _ = m(x, adj)
+    assert ops.LAST_WS_FLOATS > 0
+    with torch.no_grad():
+        y0, _ = m(x, adj)
+    assert ops.LAST_WS_FLOATS == 0
+    assert _maxdiff(y0.cpu().numpy(), y1.detach().cpu().numpy()) < 1e-6
 
 
 def test_inference_matches_training_forward(dev):
@@ -614,7 +630,7 @@ def test_empty_and_degenerate_batches(dev):
     tot.backward()
     errs = _grad_errors(((name, p.grad) for name, p in m.named_parameters()),
                         lambda name: None if params[name].grad is None else params[name].grad.numpy())
-    bad = {k: e for k, e in errs.items() if e > 2e-4}
+    bad = {k: e for k, e in errs.items() if e > 5e-5}           # measured worst case 3.4e-6 (V = 128)
     assert not bad, bad
     for k, val in m.state_dict().items():
         if "running" in k:
@@ -726,13 +742,13 @@ def test_every_crowd_size_of_the_wave_path(dev):
         assert _maxdiff(losses.detach().cpu().numpy(), torch.stack(ref_losses).detach().numpy()) < 5e-5, v
         errs = _grad_errors(((name, p.grad) for name, p in m.named_parameters()),
                             lambda name: None if params[name].grad is None else params[name].grad.numpy())
-        bad = {k: e for k, e in errs.items() if e > 2e-4}
+        bad = {k: e for k, e in errs.items() if e > 1e-4}       # measured worst case 2.4e-5 (V = 1)
         assert not bad, (v, bad)
         worst[v] = max(errs.values())
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
     print("crowd-size sweep 1..70, worst relative gradient error vs the fp64 oracle:",
           ", ".join("V=%d %.1e" % kv for kv in top))
-    assert max(worst.values()) < 2e-4
+    assert max(worst.values()) < 1e-4
 
 
 def test_split_bf16_input_gradient_variant(dev, monkeypatch):
