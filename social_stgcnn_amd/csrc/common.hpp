@@ -46,6 +46,10 @@ struct EventList {
         if (ev && next < n) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[next]), st);
         ++next;
     }
+    // record the events the entry point did not reach, so that every handle the caller passed can be read back
+    void finish() {
+        while (ev && next < n) mark();
+    }
 };
 
 constexpr int kWave = 64;           // gfx950 wavefront

@@ -69,7 +69,10 @@ struct WgradArgs {
 // ceil(V_n / kWgradChunkV) equal column chunks (each with its two halo columns of the plane), every chunk one work
 // item whose LDS image -- and MFMA loop -- is that of a small scene.  The weight gradient is a sum over positions,
 // so chunks simply add.  Keeps the image at 19 KB per wave (8 waves per CU) for every V.
-constexpr int kWgradChunkV = 32;
+#ifndef STG_WGRAD_CHUNK
+#define STG_WGRAD_CHUNK 32
+#endif
+constexpr int kWgradChunkV = STG_WGRAD_CHUNK;
 __host__ __device__ inline int wgrad_chunks(int V) { return (V + kWgradChunkV - 1) / kWgradChunkV; }
 __host__ __device__ inline int wgrad_image_v(int V) { return V < kWgradChunkV ? V : kWgradChunkV; }
 __host__ __device__ inline int wgrad_image_floats(int V0) {
@@ -629,7 +632,8 @@ static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
     g->waves = waves;
     g->lds = per_wave * waves;
     int per_cu = (int)(kLdsBytes / g->lds);
-    if (per_cu * waves > 8) per_cu = 8 / waves > 0 ? 8 / waves : 1;
+    const int max_waves = diag_env("STG_WGRAD_MAXW", 8);       // resident waves per CU
+    if (per_cu * waves > max_waves) per_cu = max_waves / waves > 0 ? max_waves / waves : 1;
     if (per_cu < 1) per_cu = 1;
     int total = kNumCU * per_cu;                       // resident workgroups on the chip
     if (const int v = diag_env("STG_WGRAD_GRID", 0)) total = v > 0 ? v : total;
@@ -848,6 +852,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((L.n_params + 7) / 8), dim3(256), 0, st, r);
     STG_LAUNCH_CHECK("stg_model_bwd: reduce_slabs");
     evl.mark();
+    evl.finish();
     return STG_OK;
 }
 

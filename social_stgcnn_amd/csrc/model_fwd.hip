@@ -301,6 +301,7 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         t.debug_skip = a.debug_skip;
         const int rcw = launch_txp_fwd_wave(t, st);
         evl.mark();
+        evl.finish();
         return rcw;
     }
     int waves = V <= 12 ? 1 : (V <= 40 ? 2 : (V <= 80 ? 4 : 8));
@@ -325,5 +326,6 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
 #undef STG_LAUNCH_FWD
     STG_LAUNCH_CHECK("stg_model_fwd");
     evl.mark();
+    evl.finish();
     return STG_OK;
 }

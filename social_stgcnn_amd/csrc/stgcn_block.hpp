@@ -80,6 +80,32 @@ __device__ __forceinline__ void block_reduce(float (&v)[K], float *red, float *t
     __syncthreads();
 }
 
+// (t, w) of column q of a scene with vi pedestrians: from the caller's position table (entry = t << 8 | w, built once
+// per scene by the wave kernels) when there is one -- no integer division by the runtime vi per column and pass
+typedef unsigned short ptab_t;
+__device__ __forceinline__ void col_of(const ptab_t *qtab, int vi, int q, int &t, int &w) {
+    if (qtab) {
+        const unsigned hw = qtab[q];
+        t = (int)(hw >> 8);
+        w = (int)(hw & 0xffu);
+    } else {
+        t = q / vi;
+        w = q - t * vi;
+    }
+}
+
+// diagnostic build: per-phase stamps of the block inside the wave kernels (slot k of the scene's 16 stamps)
+#ifdef STG_DIAG
+#define STG_BLK_STAMP(k)                                                                                              \
+    do {                                                                                                              \
+        if constexpr (WAVES == 0) {                                                                                   \
+            if (a.stamps && (threadIdx.x & 63) == 0) a.stamps[(int64_t)n * 16 + (k)] = __builtin_amdgcn_s_memtime();  \
+        }                                                                                                             \
+    } while (0)
+#else
+#define STG_BLK_STAMP(k) do { } while (0)
+#endif
+
 // What the block code needs from its caller's argument block (FwdArgs / BwdArgs / TxpFwdArgs / TxpBwdArgs all carry
 // these members): lay, V, adj, a_sn, x, x_sn, x_sc, x_st, x_sv.
 
@@ -100,7 +126,7 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
                                 const BlockLayout &b, int n, int vi, const float *X, float *G, float *H, float *red,
                                 float *wsn, float *statn, const float *pre_ax, const float *pre_cs, bool to_txp,
                                 float *plane, int plane_sc, float *plane_base, int plane_zero_f4, float *yblock,
-                                bool save_s) {
+                                bool save_s, const ptab_t *qtab = nullptr) {
     constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT;
     using S = Scope<WAVES>;
     constexpr int NT = S::NT;
@@ -116,7 +142,8 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
     for (int c = 0; c < C; ++c) s1[c] = 0.f;
     if (pre_ax) {
         for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
+            int t, w;
+            col_of(qtab, vi, q, t, w);
             float ax[CIN];
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) ax[ci] = pre_ax[(ci * T + t) * vi + w];
@@ -134,7 +161,8 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
     } else {
         const float *an = a.adj + n * a.a_sn;
         for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
+            int t, w;
+            col_of(qtab, vi, q, t, w);
             float ax[CIN];
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) ax[ci] = 0.f;
@@ -172,6 +200,7 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
             }
         }
     }
+    STG_BLK_STAMP(10);
     // ---- BatchNorm tcn.0 statistics (model.py:114) ------------------------------------------------
     float m1[C], r1[C];
     if (train) {
@@ -181,7 +210,8 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
         for (int c = 0; c < C; ++c) { m1[c] = s1[c] / (float)cnt; s2[c] = 0.f; }
         S::sync();   // G complete
         for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
+            int t, w;
+            col_of(qtab, vi, q, t, w);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const float d = G[(c * T + t) * vi + w] - m1[c];
@@ -212,11 +242,13 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
             wsn[b.ws_hdr + C + c] = r1[c];
         }
     }
+    STG_BLK_STAMP(11);
     // ---- P3: BN + PReLU in place (tcn.0, tcn.1) --------------------------------------------------
     {
         const float al = P_[b.prelu1];
         for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
+            int t, w;
+            col_of(qtab, vi, q, t, w);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const int i = (c * T + t) * vi + w;
@@ -226,15 +258,22 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
         }
     }
     S::sync();
+    STG_BLK_STAMP(12);
     // ---- P4: temporal conv (tcn.2) + residual 1x1 conv statistics -------------------------------
     float s2r[2 * C];
 #pragma unroll
     for (int c = 0; c < 2 * C; ++c) s2r[c] = 0.f;
+    float tw[C * C * KT], tb[C];        // temporal conv weights: registers for the pass
+#pragma unroll
+    for (int k = 0; k < C * C * KT; ++k) tw[k] = P_[b.tcn_w + k];
+#pragma unroll
+    for (int c = 0; c < C; ++c) tb[c] = P_[b.tcn_b + c];
     for (int q = tid; q < cnt; q += NT) {
-        const int t = q / vi, w = q - t * vi;
+        int t, w;
+            col_of(qtab, vi, q, t, w);
         float h[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) h[c] = P_[b.tcn_b + c];
+        for (int c = 0; c < C; ++c) h[c] = tb[c];
 #pragma unroll
         for (int dt = 0; dt < KT; ++dt) {
             const int ti = t + dt - (KT - 1) / 2;
@@ -243,7 +282,7 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
             for (int ci = 0; ci < C; ++ci) {
                 const float hv = G[(ci * T + ti) * vi + w];
 #pragma unroll
-                for (int c = 0; c < C; ++c) h[c] = fmaf(P_[b.tcn_w + (c * C + ci) * KT + dt], hv, h[c]);
+                for (int c = 0; c < C; ++c) h[c] = fmaf(tw[(c * C + ci) * KT + dt], hv, h[c]);
             }
         }
 #pragma unroll
@@ -262,6 +301,7 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
             }
         }
     }
+    STG_BLK_STAMP(13);
     float m2[C], r2[C], mr[C], rr[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) { mr[c] = 0.f; rr[c] = 0.f; }
@@ -277,7 +317,8 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
         }
         S::sync();   // H complete
         for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
+            int t, w;
+            col_of(qtab, vi, q, t, w);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const float d = H[(c * T + t) * vi + w] - m2[c];
@@ -330,6 +371,7 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
             wsn[b.ws_hdr + 5 * C + c] = rr[c];
         }
     }
+    STG_BLK_STAMP(14);
     // ---- P6: BN (tcn.3) + residual + PReLU (model.py:150-153) ------------------------------------
     const float ao = P_[b.prelu_o];
     const int SW = txp_sw(vi), SC = plane_sc;
@@ -354,7 +396,8 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
         for (int k = 0; k < kWaveMaxCols; ++k) {
             const int q = tid + 64 * k;
             if (q < cnt) {
-                const int t = q / vi, w = q - t * vi;
+                int t, w;
+            col_of(qtab, vi, q, t, w);
 #pragma unroll
                 for (int c = 0; c < C; ++c) sv[k][c] = out_value(c, t, w);
             }
@@ -369,7 +412,8 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
         for (int k = 0; k < kWaveMaxCols; ++k) {
             const int q = tid + 64 * k;
             if (q < cnt) {
-                const int t = q / vi, w = q - t * vi;
+                int t, w;
+            col_of(qtab, vi, q, t, w);
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const float s = sv[k][c];
@@ -386,7 +430,8 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
         }
     } else {
         for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
+            int t, w;
+            col_of(qtab, vi, q, t, w);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const int i = (c * T + t) * vi + w;
@@ -417,7 +462,8 @@ __device__ __forceinline__ void stgcn_block_bwd(const Args &a, const float *P_, 
                                 float *D, float *H1,
                                 float *DH2, float *DB1, float *red, float *tot, float *gsm, const float *wsn,
                                 const float *xin_ws /* block input saved by the previous block, or null */,
-                                float *dxs, float *dxg, const float *lds_saved /* staged [ax|cs|g|h2] or null */) {
+                                float *dxs, float *dxg, const float *lds_saved /* staged [ax|cs|g|h2] or null */,
+                                const ptab_t *qtab = nullptr) {
     constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, TP = T + 2;
     using S = Scope<WAVES>;
     constexpr int NT = S::NT;
@@ -475,7 +521,8 @@ __device__ __forceinline__ void stgcn_block_bwd(const Args &a, const float *P_, 
             H1[(c * TP + T + 1) * vi + w] = 0.f;
         }
         for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
+            int t, w;
+            col_of(qtab, vi, q, t, w);
             float xv[CIN];
             if (b.residual != 0) {
 #pragma unroll
@@ -550,7 +597,8 @@ __device__ __forceinline__ void stgcn_block_bwd(const Args &a, const float *P_, 
         }
         S::sync();       // (wave mode: the totals above were read from LDS before the next reduction overwrites them)
         for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
+            int t, w;
+            col_of(qtab, vi, q, t, w);
             float xv[CIN];
             if (b.residual == 2) {
 #pragma unroll
@@ -595,7 +643,8 @@ __device__ __forceinline__ void stgcn_block_bwd(const Args &a, const float *P_, 
 #pragma unroll
         for (int k = 0; k < C * C; ++k) s[k] = 0.f;
         for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
+            int t, w;
+            col_of(qtab, vi, q, t, w);
             float dh[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) dh[c] = DH2[(c * TP + t + 1) * vi + w];
@@ -624,7 +673,8 @@ __device__ __forceinline__ void stgcn_block_bwd(const Args &a, const float *P_, 
 #pragma unroll
         for (int c = 0; c < C; ++c) { g1[c] = P_[b.bn1_g + c]; b1p[c] = P_[b.bn1_b + c]; }
         for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
+            int t, w;
+            col_of(qtab, vi, q, t, w);
             float dh1[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
@@ -686,7 +736,8 @@ __device__ __forceinline__ void stgcn_block_bwd(const Args &a, const float *P_, 
         }
         S::sync();       // (wave mode: mdb / mdbx were read from LDS before the next reduction overwrites them)
         for (int q = tid; q < cnt; q += NT) {
-            const int t = q / vi, w = q - t * vi;
+            int t, w;
+            col_of(qtab, vi, q, t, w);
             float axv[CIN], dax[CIN];
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) {
@@ -721,7 +772,8 @@ __device__ __forceinline__ void stgcn_block_bwd(const Args &a, const float *P_, 
             // ---- B5: dx[ci][t][v] = sum_w dax[ci][t][w] A[t][v][w] + residual path -----------------
             const float *an = a.adj + n * a.a_sn;
             for (int q = tid; q < cnt; q += NT) {
-                const int t = q / vi, v = q - t * vi;
+                int t, v;
+                col_of(qtab, vi, q, t, v);
                 float acc[CIN];
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.f;

@@ -23,10 +23,13 @@ namespace {
 
 constexpr int C = Cfg::C, P = Cfg::P, T = Cfg::T;
 
-// the backward's position table doubles as the st_gcn tail's 32 reduction totals
-__host__ __device__ inline int bwd_ptab_floats(int v) {
-    const int t = (C * v + 3) & ~3;
-    return t > kRedMax ? t : kRedMax;
+// LDS floats of one wave's position table (16-bit entries, T * v of them) [+ the st_gcn tail's 32 reduction totals]
+__host__ __device__ inline int ptab_floats(int v) { return ((T * v + 1) / 2 + 3) & ~3; }
+__host__ __device__ inline int bwd_ptab_floats(int v) { return ptab_floats(v) + kRedMax; }
+// LDS floats of the workgroup's copy of the st_gcn block parameters and BatchNorm running statistics: the block code
+// of the wave kernels reads them with broadcast LDS reads (no SGPR pressure, no scalar-load waits inside its passes)
+__host__ __device__ inline int wave_param_floats(const ModelLayout &L) {
+    return ((L.n_blk_params + 3) & ~3) + ((L.n_buffers + 3) & ~3);
 }
 
 // A lane's weights of one (co, ci) pair are 9 consecutive floats (the taps): two 16-byte loads + one dword per pair
@@ -80,16 +83,18 @@ struct TileGeom {
     bool ok[2];
 };
 
-// position -> (h << 16 | w) table of the scene (one LDS word per position; no integer divisions per tile)
-__device__ __forceinline__ void build_ptab(unsigned *ptab, int vi, int npos) {
+// position -> (h << 8 | w) table of the scene, T * vi entries of 16 bits: p < C * vi are the positions of the TXP
+// plane, q < T * vi the (t, w) columns of the st_gcn block -- no integer divisions per tile / column
+__device__ __forceinline__ void build_ptab(ptab_t *ptab, int vi) {
     const int lane = threadIdx.x & 63;
-    for (int p = lane; p < npos; p += 64) {
+    for (int p = lane; p < T * vi; p += 64) {
         const int h = p / vi;
-        ptab[p] = ((unsigned)h << 16) | (unsigned)(p - h * vi);
+        ptab[p] = (ptab_t)((h << 8) | (p - h * vi));
     }
 }
 
-__device__ __forceinline__ TileGeom tile_geom(int tile0, const unsigned *ptab, int npos) {
+
+__device__ __forceinline__ TileGeom tile_geom(int tile0, const ptab_t *ptab, int npos) {
     const int nq = threadIdx.x & 15;
     TileGeom g;
 #pragma unroll
@@ -98,8 +103,8 @@ __device__ __forceinline__ TileGeom tile_geom(int tile0, const unsigned *ptab, i
         g.ok[u] = p < npos;
         g.pos[u] = g.ok[u] ? p : 0;
         const unsigned hw = ptab[g.pos[u]];
-        g.hh[u] = (int)(hw >> 16);
-        g.ww[u] = (int)(hw & 0xffffu);
+        g.hh[u] = (int)(hw >> 8);
+        g.ww[u] = (int)(hw & 0xffu);
     }
     return g;
 }
@@ -153,7 +158,7 @@ __device__ __forceinline__ void mma_pair(const float (&wreg)[9 * KJ], const BReg
 // forward's odd layers: their writes land two rows ABOVE the rows still to be read).
 template <int KJ, bool REV = false, typename Epi>
 __device__ __forceinline__ void conv_tiles(const float (&wreg)[9 * KJ], const f32x4 binit,
-                                           const float *plane, const unsigned *ptab, int npos, int SW,
+                                           const float *plane, const ptab_t *ptab, int npos, int SW,
                                            int SC, Epi epi) {
     const int ntiles = (npos + 15) >> 4;
     const int npairs = (ntiles + 1) >> 1;
@@ -200,7 +205,7 @@ __device__ __forceinline__ void wave_dma(const float *__restrict__ src, float *l
 // SC = txp_sci(vi)); they differ by two row slots and alias, hence no __restrict__.
 template <int CINL, int KIND, bool REV>
 __device__ __forceinline__ void fwd_layer(const float (&wreg)[CINL * 9 / 4], const float *__restrict__ bias, float alpha,
-                                          const float *in, float *out, const unsigned *ptab,
+                                          const float *in, float *out, const ptab_t *ptab,
                                           int vi, int V, float *zsave, float *psave, float *yout) {
     const int kq = (threadIdx.x & 63) >> 4;
     const int SW = txp_sw(vi), SC = txp_sci(vi), npos = C * vi;
@@ -262,13 +267,23 @@ __device__ __forceinline__ void zero_row_slot(float *buf, int slot_row, int SW, 
         for (int c = lane; c < SW; c += 64) row[ch * SC + c] = 0.f;
 }
 
+// Workgroup prologue of the wave kernels: the st_gcn block's parameters (and running statistics) into LDS, once.
+__device__ __forceinline__ void stage_block_params(const ModelLayout &L, const float *__restrict__ params,
+                                                   const float *__restrict__ buffers, float *blk_p, float *blk_b, int nt) {
+    for (int e = threadIdx.x; e < L.n_blk_params; e += nt) blk_p[e] = params[e];
+    if (buffers)
+        for (int e = threadIdx.x; e < L.n_buffers; e += nt) blk_b[e] = buffers[e];
+    __syncthreads();
+}
+
 // One scene-window, whole model.  `buf` = the wave's LDS region: the in-place TXP plane image [P][txp_sci(vi)], which
 // during the st_gcn block phase holds the block's arrays instead -- G [C][T][vi] at the start, the block input X
 // [CIN0][T][vi] behind it, H [C][T][vi] at the END of the image (96 vi <= P txp_sci(vi) - 40 vi always).  The block
 // forms its outputs in registers, zeroes the image and scatters a_0 into it (stgcn_block_fwd, wave mode): the block
 // output never visits HBM on its way to the TXP-CNN.
 __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, const float *__restrict__ params,
-                                              const float *__restrict__ buffers, int n, float *buf, unsigned *ptab) {
+                                              const float *blk_params, const float *blk_buffers, int n, float *buf,
+                                              ptab_t *ptab) {
     const ModelLayout &L = a.lay;
     const int V = a.V, lane = threadIdx.x & 63;
     STG_STAMP(0);
@@ -294,11 +309,13 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, const float *
             const int v = e % vi, ct = e / vi, t = ct % T, c = ct / T;
             X[e] = xn[c * a.x_sc + t * a.x_st + v * a.x_sv];
         }
-        build_ptab(ptab, vi, C * vi);
+        build_ptab(ptab, vi);
         __builtin_amdgcn_wave_barrier();
+        STG_STAMP(9);
         const float *agn = a.agg + n * a.agg_stride;
-        stgcn_block_fwd<Cfg::CIN0, 0>(a, params, buffers, L.blk[0], n, vi, X, G, H, nullptr, wsn, statn, agn + a.agg_ax,
-                                      agn + a.agg_cs, true, buf + 2 * SW, SC, buf, (P * SC) >> 2, nullptr, false);
+        stgcn_block_fwd<Cfg::CIN0, 0>(a, blk_params, blk_buffers, L.blk[0], n, vi, X, G, H, nullptr, wsn, statn,
+                                      agn + a.agg_ax, agn + a.agg_cs, true, buf + 2 * SW, SC, buf, (P * SC) >> 2,
+                                      nullptr, false, ptab);
     }
     STG_STAMP(1);
     // a_0 now sits in the in-place layout (T channels, rows at slot offset 2, zeros elsewhere)
@@ -383,9 +400,11 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Vl = a.Vl, wave = threadIdx.x >> 6;
     const int slot = P * txp_sci(Vl);
-    const int per_wave = slot + ((C * Vl + 3) & ~3);
+    const int per_wave = slot + ptab_floats(Vl);
     float *pa = sm + wave * per_wave;
-    unsigned *ptab = reinterpret_cast<unsigned *>(pa + slot);
+    ptab_t *ptab = reinterpret_cast<ptab_t *>(pa + slot);
+    float *blk_p = sm + WPB * per_wave, *blk_b = blk_p + ((a.lay.n_blk_params + 3) & ~3);
+    stage_block_params(a.lay, params, buffers, blk_p, blk_b, WPB * 64);
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;
     int begin, end;
     tier_range(a.tier, a.N, a.V, begin, end);
@@ -394,7 +413,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
         const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
-        txp_fwd_scene(a, params, buffers, n, pa, ptab);
+        txp_fwd_scene(a, params, blk_p, blk_b, n, pa, ptab);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -404,7 +423,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
 // ------------------------------------------------------------------------------------------
 template <int CINL>
 __device__ __forceinline__ void dgrad_layer(const float (&wreg)[27], const float *__restrict__ dzb,
-                                            float *__restrict__ dcur, const unsigned *ptab, int vi, bool accumulate) {
+                                            float *__restrict__ dcur, const ptab_t *ptab, int vi, bool accumulate) {
     const int kq = (threadIdx.x & 63) >> 4;
     const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -424,14 +443,13 @@ __device__ __forceinline__ void dgrad_layer(const float (&wreg)[27], const float
 // LDS arrays are carved from the start of the wave's region: D = d(block output) [C][T][vi] | h1 [C][T+2][vi] | dh2
 // [C][T+2][vi] (140 vi floats <= plane_slot + 60 V); db1 reuses D.  Small-parameter gradients leave as the scene's own
 // row (stores, no atomics): reduce_slabs_kernel sums the rows in a fixed order.
-__device__ __forceinline__ void txp_bwd_block_tail(const TxpBwdArgs &a, int n, int vi, float *dzb, float *dcur,
-                                                   unsigned *ptab, float *slope_row) {
+__device__ __forceinline__ void txp_bwd_block_tail(const TxpBwdArgs &a, const float *blk_params, int n, int vi,
+                                                   float *dzb, float *dcur, ptab_t *ptab, float *tot, float *slope_row) {
     const ModelLayout &L = a.lay;
     const int lane = threadIdx.x & 63;
     for (int e = L.L + lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;       // dead slopes (layers >= L)
     if (STG_SKIP(a, 4)) return;
     float *D = dzb, *H1 = dzb + C * T * vi, *DH2 = H1 + C * (T + 2) * vi;
-    float *tot = reinterpret_cast<float *>(ptab);          // (the position table is dead too: 32 floats of totals)
     // v.view(N, T, C, V) (model.py:187) backwards: plane (ch, row) is flat f = ch*C + row = c*T + t of the block output
     for (int f = 0; f < C * T; ++f) {
         const int ch = f / C, row = f - ch * C;
@@ -439,11 +457,12 @@ __device__ __forceinline__ void txp_bwd_block_tail(const TxpBwdArgs &a, int n, i
     }
     __builtin_amdgcn_wave_barrier();
     float *row = slope_row - L.n_blk_params;
-    stgcn_block_bwd<Cfg::CIN0, 0, false>(a, a.params, L.blk[0], n, vi, D, H1, DH2, D, nullptr, tot, row,
-                                         a.ws + n * a.ws_stride, nullptr, nullptr, nullptr, nullptr);
+    stgcn_block_bwd<Cfg::CIN0, 0, false>(a, blk_params, L.blk[0], n, vi, D, H1, DH2, D, nullptr, tot, row,
+                                         a.ws + n * a.ws_stride, nullptr, nullptr, nullptr, nullptr, ptab);
 }
 
-__device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float *dzb, float *dcur, unsigned *ptab) {
+__device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, const float *blk_params, int n, float *dzb, float *dcur,
+                                              ptab_t *ptab, float *tot) {
     const ModelLayout &L = a.lay;
     const int V = a.V, lane = threadIdx.x & 63;
     int vi = a.num_peds ? a.num_peds[n] : V;
@@ -458,7 +477,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
     const float *wsn = a.ws + n * a.ws_stride;
     const float *dyn = a.dy + (int64_t)n * (C * P) * V;
     wave_zero(dzb, (P * SC) >> 2);
-    build_ptab(ptab, vi, npos);
+    build_ptab(ptab, vi);
     float wr[27];
     load_w_bwd<P>(Pm + L.out_w, wr);
     __builtin_amdgcn_wave_barrier();
@@ -517,7 +536,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
                     if (vv < nvec) {
                         const int p = vv / 3, q = vv - p * 3;       // position, channel quad
                         const unsigned hw = ptab[p];
-                        const int h = (int)(hw >> 16), w = (int)(hw & 0xffffu);
+                        const int h = (int)(hw >> 8), w = (int)(hw & 0xffu);
                         f32x4 dzv;
                         const f32x4 dv = reinterpret_cast<const f32x4 *>(dcur)[vv];   // [pos][P]: vector vv = (p, q)
 #pragma unroll
@@ -551,7 +570,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, int n, float 
         }
         __builtin_amdgcn_wave_barrier();
     }
-    txp_bwd_block_tail(a, n, vi, dzb, dcur, ptab, slope_row);
+    txp_bwd_block_tail(a, blk_params, n, vi, dzb, dcur, ptab, tot, slope_row);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -599,7 +618,7 @@ __device__ __forceinline__ void load_w_bwd_bf16(const float *__restrict__ W, s16
 
 template <int CINL>
 __device__ __forceinline__ void dgrad_layer_bf16(const s16x4 (&whi)[9], const s16x4 (&wlo)[9], const char *hi,
-                                                 const char *lo, float *__restrict__ dcur, const unsigned *ptab, int vi,
+                                                 const char *lo, float *__restrict__ dcur, const ptab_t *ptab, int vi,
                                                  bool accumulate) {
     const int kq = (threadIdx.x & 63) >> 4, kc = kq < 3 ? kq : 2;       // lanes kq = 3: finite data x zero weights
     const int SW = txp_sw(vi), npos = C * vi;
@@ -640,7 +659,8 @@ __device__ __forceinline__ void dgrad_layer_bf16(const s16x4 (&whi)[9], const s1
     }
 }
 
-__device__ __forceinline__ void txp_bwd_scene_bf16(const TxpBwdArgs &a, int n, float *dzb, float *dcur, unsigned *ptab) {
+__device__ __forceinline__ void txp_bwd_scene_bf16(const TxpBwdArgs &a, const float *blk_params, int n, float *dzb,
+                                                   float *dcur, ptab_t *ptab, float *tot) {
     const ModelLayout &L = a.lay;
     const int V = a.V, lane = threadIdx.x & 63;
     int vi = a.num_peds ? a.num_peds[n] : V;
@@ -656,7 +676,7 @@ __device__ __forceinline__ void txp_bwd_scene_bf16(const TxpBwdArgs &a, int n, f
     const float *dyn = a.dy + (int64_t)n * (C * P) * V;
     char *hi = reinterpret_cast<char *>(dzb), *lo = hi + npad * 24;          // 2 * npad * 24 B <= P * SC * 4 B
     wave_zero(dzb, (P * SC) >> 2);
-    build_ptab(ptab, vi, npos);
+    build_ptab(ptab, vi);
     s16x4 whi[9], wlo[9];
     load_w_bwd_bf16<P>(Pm + L.out_w, whi, wlo);
     __builtin_amdgcn_wave_barrier();
@@ -712,7 +732,7 @@ __device__ __forceinline__ void txp_bwd_scene_bf16(const TxpBwdArgs &a, int n, f
                     if (vv < nvec) {
                         const int p = vv / 3, q = vv - p * 3;
                         const unsigned hw = ptab[p];
-                        const int h = (int)(hw >> 16), w = (int)(hw & 0xffffu);
+                        const int h = (int)(hw >> 8), w = (int)(hw & 0xffu);
                         const f32x4 dv = reinterpret_cast<const f32x4 *>(dcur)[vv];
                         f32x4 dzv;
                         float x[4];
@@ -750,7 +770,7 @@ __device__ __forceinline__ void txp_bwd_scene_bf16(const TxpBwdArgs &a, int n, f
         }
         __builtin_amdgcn_wave_barrier();
     }
-    txp_bwd_block_tail(a, n, vi, dzb, dcur, ptab, slope_row);
+    txp_bwd_block_tail(a, blk_params, n, vi, dzb, dcur, ptab, tot, slope_row);
 }
 
 template <int WPB, bool BF16>
@@ -760,7 +780,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) void txp_bwd_wave_kerne
     const int slot = plane_slot(Vl);
     const int per_wave = slot + P * C * Vl + bwd_ptab_floats(Vl);
     float *dzb = sm + wave * per_wave, *dcur = dzb + slot;
-    unsigned *ptab = reinterpret_cast<unsigned *>(dcur + P * C * Vl);
+    ptab_t *ptab = reinterpret_cast<ptab_t *>(dcur + P * C * Vl);
+    float *tot = dcur + P * C * Vl + ptab_floats(Vl);
+    float *blk_p = sm + WPB * per_wave;
+    stage_block_params(a.lay, a.params, nullptr, blk_p, nullptr, WPB * 64);
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;
     int begin, end;
     tier_range(a.tier, a.N, a.V, begin, end);
@@ -769,8 +792,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) void txp_bwd_wave_kerne
         const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
-        if (BF16) txp_bwd_scene_bf16(a, n, dzb, dcur, ptab);      // (separate instantiations: the variants
-        else txp_bwd_scene(a, n, dzb, dcur, ptab);               //  do not share a register budget)
+        if (BF16) txp_bwd_scene_bf16(a, blk_p, n, dzb, dcur, ptab, tot);      // (separate instantiations: the variants
+        else txp_bwd_scene(a, blk_p, n, dzb, dcur, ptab, tot);               //  do not share a register budget)
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -836,18 +859,20 @@ __device__ __forceinline__ MixSlot mix_assign(const SceneTier &t, const MixGeom 
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_fwd_wave_mixed_kernel(
     const TxpFwdArgs a, const float *__restrict__ params, const float *__restrict__ buffers) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *blk_p = sm + a.mix.block_floats, *blk_b = blk_p + ((a.lay.n_blk_params + 3) & ~3);
+    stage_block_params(a.lay, params, buffers, blk_p, blk_b, 256);
     const MixSlot m = mix_assign(a.tier, a.mix, a.N, a.V);
     if (!m.active) return;
     const int wave = threadIdx.x >> 6;
     const int slot = P * txp_sci(m.vc);                 // region = [in-place plane | ptab] of the class's largest scene
     float *pa = sm + wave * m.region;
-    unsigned *ptab = reinterpret_cast<unsigned *>(pa + slot);
+    ptab_t *ptab = reinterpret_cast<ptab_t *>(pa + slot);
     const int M = m.end - m.begin;
     for (int r = 0; r * m.nworkers < M; ++r) {
         const int it = walk_item(r, m.worker, m.nworkers, M, a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order[m.begin + it]);
-        txp_fwd_scene(a, params, buffers, n, pa, ptab);
+        txp_fwd_scene(a, params, blk_p, blk_b, n, pa, ptab);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -855,19 +880,22 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 template <bool BF16>
 __global__ __launch_bounds__(256, 2) void txp_bwd_wave_mixed_kernel(const TxpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *blk_p = sm + a.mix.block_floats;
+    stage_block_params(a.lay, a.params, nullptr, blk_p, nullptr, 256);
     const MixSlot m = mix_assign(a.tier, a.mix, a.N, a.V);
     if (!m.active) return;
     const int wave = threadIdx.x >> 6;
-    const int slot = plane_slot(m.vc);                  // region = [dz plane | dcur | ptab] of the class's largest scene
+    const int slot = plane_slot(m.vc);                  // region = [dz plane | dcur | ptab | totals] of the class's largest scene
     float *dzb = sm + wave * m.region, *dcur = dzb + slot;
-    unsigned *ptab = reinterpret_cast<unsigned *>(dcur + P * C * m.vc);
+    ptab_t *ptab = reinterpret_cast<ptab_t *>(dcur + P * C * m.vc);
+    float *tot = dcur + P * C * m.vc + ptab_floats(m.vc);
     const int M = m.end - m.begin;
     for (int r = 0; r * m.nworkers < M; ++r) {
         const int it = walk_item(r, m.worker, m.nworkers, M, a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order[m.begin + it]);
-        if (BF16) txp_bwd_scene_bf16(a, n, dzb, dcur, ptab);      // (separate instantiations: the variants
-        else txp_bwd_scene(a, n, dzb, dcur, ptab);               //  do not share a register budget)
+        if (BF16) txp_bwd_scene_bf16(a, blk_p, n, dzb, dcur, ptab, tot);      // (separate instantiations: the variants
+        else txp_bwd_scene(a, blk_p, n, dzb, dcur, ptab, tot);               //  do not share a register budget)
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -907,7 +935,7 @@ bool txp_wave_fits(const ModelLayout &L, int V) {
     return fwd <= 48 * 1024;        // at least three waves per CU
 }
 
-static size_t fwd_per_wave_floats(int v) { return (size_t)P * txp_sci(v) + ((C * v + 3) & ~3); }
+static size_t fwd_per_wave_floats(int v) { return (size_t)P * txp_sci(v) + ptab_floats(v); }
 static size_t bwd_per_wave_floats(int v) { return (size_t)plane_slot(v) + (size_t)P * C * v + bwd_ptab_floats(v); }
 constexpr int kMixSmallV = 32;
 
@@ -937,7 +965,7 @@ static int mix_grid(size_t lds_bytes, int N) {
 int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
     TxpFwdArgs a = a0;
     if (mix_geom(fwd_per_wave_floats, a.V, a.tier.order && a.tier.key_start, &a.mix)) {
-        const size_t lds = (size_t)a.mix.block_floats * sizeof(float);
+        const size_t lds = ((size_t)a.mix.block_floats + wave_param_floats(a.lay)) * sizeof(float);
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_fwd_wave_mixed_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e_ != hipSuccess) return hip_fail(e_, "txp_fwd_wave_mixed: hipFuncSetAttribute");
@@ -947,7 +975,7 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
     }
     const size_t per_wave = fwd_per_wave_floats(a.Vl) * sizeof(float);
     const int wpb = wave_wpb(per_wave);
-    const size_t lds = per_wave * wpb;
+    const size_t lds = per_wave * wpb + wave_param_floats(a.lay) * sizeof(float);
     const dim3 grid(wave_grid(lds, wpb, a.N));
 #define STG_L(W)                                                                                              \
     do {                                                                                                      \
@@ -965,7 +993,7 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
 int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {
     TxpBwdArgs a = a0;
     if (mix_geom(bwd_per_wave_floats, a.V, a.tier.order && a.tier.key_start, &a.mix)) {
-        const size_t lds = (size_t)a.mix.block_floats * sizeof(float);
+        const size_t lds = ((size_t)a.mix.block_floats + wave_param_floats(a.lay)) * sizeof(float);
         const void *fn = a.split_bf16 ? reinterpret_cast<const void *>(&txp_bwd_wave_mixed_kernel<true>)
                                       : reinterpret_cast<const void *>(&txp_bwd_wave_mixed_kernel<false>);
         hipError_t e_ = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -979,7 +1007,7 @@ int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {
     }
     const size_t per_wave = bwd_per_wave_floats(a.Vl) * sizeof(float);
     const int wpb = wave_wpb(per_wave);
-    const size_t lds = per_wave * wpb;
+    const size_t lds = per_wave * wpb + wave_param_floats(a.lay) * sizeof(float);
     const dim3 grid(wave_grid(lds, wpb, a.N));
 #define STG_L2(W, B)                                                                                          \
     do {                                                                                                      \

@@ -207,6 +207,7 @@ class KernelTimer:
             for k in range(1, ev.n):
                 ms = ctypes.c_float()
                 if hip.hipEventElapsedTime(ctypes.byref(ms), ev.arr[k - 1], ev.arr[k]) != 0:
+                    hip.hipGetLastError()          # (an unrecorded handle: clear the runtime's sticky error)
                     break
                 row.append(ms.value)
             rows.append(row)

@@ -1,6 +1,7 @@
 """Diagnostic (STG_STAMPS=1): per-phase wave timelines of txp_fwd_wave_kernel."""
 import os, sys
 os.environ["STG_STAMPS"] = "1"
+os.environ["STG_USE_DIAG_LIB"] = "1"        # stamps exist only in the diagnostic build (make -C csrc DIAG=1)
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench
@@ -21,8 +22,7 @@ else:
     for _ in range(3): m(x, adj)
 torch.cuda.synchronize()
 scr = ops.LAST_FWD_SCRATCH
-slot = 8 * 336                       # a0_slot(32) = T * txp_sci(32)
-off = ((n * slot + 3) & ~3) + 4 + ((n + v + 2 + 3) & ~3)     # a_0 planes, pad, scene order
+off = ((n * 3 * 8 * v + 3) & ~3) + 4 + ((n + v + 2 + 3) & ~3)     # aggregated input, pad, scene order
 st = scr[off: off + n * 32].cpu().numpy().view(np.uint64).reshape(n, 16).astype(np.int64)
 t0 = st[:, 0].min()
 print("kernel span (cycles): %d   scenes: %d" % (st[:, 8].max() - t0, n))
@@ -31,12 +31,20 @@ names = ["dma+w0 wait", "layer0", "layer1", "layer2", "layer3", "(unused)", "(un
 for k in range(8):
     if k in (5, 6): continue
     col = d[:, k] if k < 5 else None
-names2 = ["stage/wait", "layer0", "layer1", "layer2", "layer3", "out"]
+names2 = ["st_gcn block", "a0 save+l0", "layer1", "layer2", "layer3", "out"]
 seg = np.stack([st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2], st[:, 4] - st[:, 3], st[:, 5] - st[:, 4], st[:, 8] - st[:, 5]], 1)
 for k, nm in enumerate(names2):
     print("%-12s median %7d  p10 %7d  p90 %7d cycles" % (nm, np.median(seg[:, k]), np.percentile(seg[:, k], 10), np.percentile(seg[:, k], 90)))
 life = st[:, 8] - st[:, 0]
 print("scene total  median %d cycles; start spread: p50 %d p90 %d max %d" % (np.median(life), np.percentile(st[:, 0] - t0, 50), np.percentile(st[:, 0] - t0, 90), (st[:, 0] - t0).max()))
+
+# st_gcn block phases (stamps 9..14 inside stgcn_block_fwd, wave mode)
+if st[:, 14].max() > 0:
+    cols = [0, 9, 10, 11, 12, 13, 14, 1]
+    nm = ["x stage+ptab", "P1 g=W ax", "BN1 stats", "P3 bn+prelu", "P4 tconv", "BN2 stats", "P6+zero+scatter"]
+    for k in range(7):
+        d_ = st[:, cols[k + 1]] - st[:, cols[k]]
+        print("  %-16s median %7d  p10 %7d  p90 %7d cycles" % (nm[k], np.median(d_), np.percentile(d_, 10), np.percentile(d_, 90)))
 
 # fine stamps of layer 1 (diagnostic build): 2 -> 12 (pointer setup + saved-border zeroing), 12 -> 9 (tile loop),
 # 9 -> 10 (weight fetch issue), 10 -> 11 (border row zeroing)
