@@ -37,6 +37,16 @@ static inline int diag_env(const char *, int dflt) { return dflt; }
 #define STG_SKIP(args, bit) false
 #endif
 
+// Desynchronise the two waves that share a SIMD: every wave of a persistent wave-per-item kernel walks the same
+// phases (stage / VALU, then MFMA) on equally sized items, so SIMD partners that start together stay in lockstep --
+// both stage, then both fight for the matrix pipe -- and nothing overlaps.  The second half of a workgroup's waves
+// (wave >= waves/2 shares a SIMD with wave - waves/2: waves are dealt to the SIMDs cyclically) starts `units` x 64 x 127
+// cycles late, about half a phase period, and from then on one partner stages while the other computes.
+__device__ __forceinline__ void stagger_start(int wave, int waves, int units) {
+    if (waves >= 2 && wave >= waves / 2)
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 // per-kernel device timing requested by the caller (stg_model_fwd / stg_model_bwd `events`)
 struct EventList {
     void **ev;
@@ -71,6 +81,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     STG_DPP_ADD(0x143, 0xc);   // row_bcast31 into rows 2, 3 -> lane 63 holds the wave sum
 #undef STG_DPP_ADD
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// K independent wave sums at once: every DPP stage is applied to all K values before the next stage, so the
+// dependent-DPP wait states of one chain are filled by the other chains (a lone wave_sum costs ~350 cycles of
+// nops and readlane hazards at two waves per SIMD; K at once ~30 cycles per value).
+template <int K>
+__device__ __forceinline__ void wave_sum_n(float (&v)[K]) {
+#define STG_DPP_STAGE(ctrl, row_mask)                                                                                \
+    _Pragma("unroll") for (int k = 0; k < K; ++k)                                                                    \
+        v[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), (ctrl), (row_mask), 0xf, false))
+    STG_DPP_STAGE(0xB1, 0xf);
+    STG_DPP_STAGE(0x4E, 0xf);
+    STG_DPP_STAGE(0x141, 0xf);
+    STG_DPP_STAGE(0x140, 0xf);
+    STG_DPP_STAGE(0x142, 0xa);
+    STG_DPP_STAGE(0x143, 0xc);
+#undef STG_DPP_STAGE
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

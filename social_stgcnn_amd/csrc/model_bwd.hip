@@ -27,6 +27,7 @@
 #include "model_common.hpp"
 #include "stgcn_block.hpp"
 #include "txp_wave.hpp"
+#include "txp_wgrad.hpp"
 
 namespace stg {
 
@@ -48,47 +49,6 @@ struct BwdArgs {
     int debug_skip;   // timing-only diagnostic (STG_DEBUG_SKIP): 1 wgrad, 2 dgrad, 4 st_gcn -- wrong results
 };
 
-// K2 arguments
-struct WgradArgs {
-    ModelLayout lay;
-    const int32_t *num_peds;
-    const int32_t *order;  // non-null: scenes sorted by crowd size (descending)
-    int serpentine;        // walk the sorted list boustrophedon (1) or with a plain stride (0)
-    int N, V;
-    const float *dy, *ws, *dzg;
-    int64_t ws_stride;
-    float *slab2;          // [layer 0..L][rows][row_len(layer)] packed, see wgrad_slab_base()
-    int rows;              // slab rows per layer = gridDim.x * WAVES
-    int wg_begin[kMaxTxp + 2];   // workgroup ranges per layer: layer l owns blocks [wg_begin[l], wg_begin[l+1])
-    int debug_skip;        // timing-only diagnostic: 64 skip staging, 128 skip the MFMA loop
-};
-
-// slab geometry of K2: layer 0 has c_in = T, layers 1..L (L = output conv) have c_in = P
-// floats of one wave-private LDS image of K2: a staged scene (plane + dz), and at the end one slab row
-// K2 stages at most kWgradChunkV pedestrian columns of a scene at a time: a larger scene is cut into
-// ceil(V_n / kWgradChunkV) equal column chunks (each with its two halo columns of the plane), every chunk one work
-// item whose LDS image -- and MFMA loop -- is that of a small scene.  The weight gradient is a sum over positions,
-// so chunks simply add.  Keeps the image at 19 KB per wave (8 waves per CU) for every V.
-#ifndef STG_WGRAD_CHUNK
-#define STG_WGRAD_CHUNK 32
-#endif
-constexpr int kWgradChunkV = STG_WGRAD_CHUNK;
-__host__ __device__ inline int wgrad_chunks(int V) { return (V + kWgradChunkV - 1) / kWgradChunkV; }
-__host__ __device__ inline int wgrad_image_v(int V) { return V < kWgradChunkV ? V : kWgradChunkV; }
-__host__ __device__ inline int wgrad_image_floats(int V0) {
-    const int V = wgrad_image_v(V0);
-    const int img = plane_slot(V) + dz_slot(V);
-    const int row = (Cfg::P * Cfg::P * 9 + Cfg::P + 3) & ~3;
-    return img > row ? img : row;
-}
-__host__ __device__ inline int wgrad_row_len(int layer) {
-    return Cfg::P * (layer == 0 ? Cfg::T : Cfg::P) * 9 + Cfg::P;
-}
-__host__ __device__ inline int64_t wgrad_slab_base(int layer, int rows) {
-    return layer == 0 ? 0 : (int64_t)rows * (wgrad_row_len(0) + (int64_t)(layer - 1) * wgrad_row_len(1));
-}
-
-__device__ __forceinline__ void wave_dma_copy(const float *__restrict__ src, float *lds_dst, int nvec);
 
 // ------------------------------------------------------------------------------------------
 // TXP-CNN backward pieces
@@ -209,6 +169,8 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
             for (int l = L.L; l >= 0; --l) {
                 const bool is_out = l == L.L;
                 if (is_out) {
+                    // (dz of the output conv is dy; it also leaves position-major for the weight-gradient GEMM)
+                    float *dzo = a.dzg + ((int64_t)n * (L.L + 1) + L.L) * dz_slot(V);
                     constexpr int U = 4;
                     for (int e0 = tid; e0 < P * npos; e0 += NT * U) {
                         float dv[U];
@@ -223,12 +185,16 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
                         }
 #pragma unroll
                         for (int u = 0; u < U; ++u)
-                            if (e0 + u * NT < P * npos) dzb[li[u]] = dv[u];
+                            if (e0 + u * NT < P * npos) {
+                                const int e = e0 + u * NT, ch = e / npos;
+                                dzb[li[u]] = dv[u];
+                                dzo[(e - ch * npos) * P + ch] = dv[u];
+                            }
                     }
                     __syncthreads();
                 } else {
                     const float *zl = wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V;
-                    float *dzo = a.dzg + ((int64_t)n * L.L + l) * dz_slot(V);
+                    float *dzo = a.dzg + ((int64_t)n * (L.L + 1) + l) * dz_slot(V);
                     const float alpha = Pm[L.prelus + l];
                     float s[1] = {0.f};
                     constexpr int U = 4;                       // z loads in flight per lane
@@ -291,233 +257,6 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
     __syncthreads();
     float *slab = a.slab1 + (int64_t)blockIdx.x * n_small;
     for (int e = tid; e < n_small; e += NT) slab[e] = gsm[e];
-}
-
-// ------------------------------------------------------------------------------------------
-// K2: TXP weight / bias gradients, one layer per blockIdx.y, waves fully independent
-// ------------------------------------------------------------------------------------------
-// Linear global -> LDS copy of `nvec` 16-byte vectors by ONE wave with LDS-DMA (global_load_lds_dwordx4:
-// every instruction moves 1 KiB, no VGPR round trip, all of them in flight at once).  The caller waits
-// with s_waitcnt vmcnt(0) before reading the image.
-__device__ __forceinline__ void wave_dma_copy(const float *__restrict__ src, float *lds_dst, int nvec) {
-    const int lane = threadIdx.x & 63;
-    for (int i = 0; i * 64 < nvec; ++i) {
-        const int e = i * 64 + lane;
-        if (e < nvec)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(src + 4 * e),
-                (__attribute__((address_space(3))) void *)(lds_dst + 256 * i), 16, 0, 0);
-    }
-}
-
-// stage columns [w0, w0 + vc) of scene n of `layer` into one wave-private LDS image: a_l (zero-bordered,
-// position-major [(C+2)*(vc+2)][P], i.e. with the two halo columns) and dz_l (position-major [C*vc][P]); LDS-DMA
-// where the source is linear (caller waits vmcnt(0)).  vc == vi (w0 = 0) is the whole scene: one linear copy each.
-template <int CINL>
-__device__ __forceinline__ void wgrad_stage(const WgradArgs &a, int layer, int n, int vi, int w0, int vc, float *plane,
-                                            float *dzs) {
-    constexpr int C = Cfg::C, P = Cfg::P;
-    const ModelLayout &L = a.lay;
-    const int V = a.V, lane = threadIdx.x & 63;
-    const int SW = txp_sw(vi), SWc = txp_sw(vc), npos = C * vc;
-    const float *wsn = a.ws + n * a.ws_stride;
-    // The saved plane holds the C interior rows with their border columns ([C*SW][P]): rows 1..C of the LDS image
-    // arrive by LDS-DMA (one linear copy for a whole scene; per row with the halo columns for a column chunk), the
-    // top and bottom border rows are zeroed here.
-    const float *pl = wsn + ws_plane_off(L, V, layer);
-    for (int e = lane; e < 2 * SWc * 3; e += 64) {
-        const int b = e / 3, q = e - b * 3;
-        const int pos = b < SWc ? b : (C + 1) * SWc + (b - SWc);
-        *reinterpret_cast<float4 *>(plane + pos * P + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (vc == vi) {
-        wave_dma_copy(pl, plane + SWc * P, (C * SW * P) >> 2);
-    } else {
-        for (int h = 0; h < C; ++h)                   // row h + 1, padded columns w0 .. w0 + vc + 1
-            wave_dma_copy(pl + (int64_t)(h * SW + w0) * P, plane + (h + 1) * SWc * P, (SWc * P) >> 2);
-    }
-    if (layer == L.L) {
-        // the output conv's dz is dy itself: (C*P) rows of V floats, vc valid from column w0 -> position-major
-        // [pos][P].  Lanes are laid over (sub-row, w) with the row length rounded up to a power of two: no division
-        // by the runtime vc
-        const float *dyn = a.dy + (int64_t)n * (C * P) * V + w0;
-        const int vp = vc <= 1 ? 1 : (vc <= 2 ? 2 : (vc <= 4 ? 4 : (vc <= 8 ? 8 : (vc <= 16 ? 16 : (vc <= 32 ? 32 : 64)))));
-        const int sh = __builtin_ctz(vp), rpi = 64 >> sh;          // rows per 64-lane pass
-        const int sub = lane >> sh, w = lane & (vp - 1);           // (vc <= kWgradChunkV <= 64: one column block)
-        constexpr int U = 4;
-        for (int r0 = 0; r0 < C * P; r0 += rpi * U) {
-            float dv[U];
-            int di[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int row = r0 + u * rpi + sub;                // row = co*C + h
-                const bool ok = w < vc && row < C * P;
-                const int rc = ok ? row : 0, co = rc / C, h = rc - co * C;
-                di[u] = ok ? (h * vc + w) * P + co : -1;
-                dv[u] = ok ? dyn[(int64_t)rc * V + w] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (di[u] >= 0) dzs[di[u]] = dv[u];
-        }
-    } else {
-        const float *dz = a.dzg + ((int64_t)n * L.L + layer) * dz_slot(V);
-        if (vc == vi) {
-            wave_dma_copy(dz, dzs, (P * npos) >> 2);
-        } else {
-            for (int h = 0; h < C; ++h)
-                wave_dma_copy(dz + (int64_t)(h * vi + w0) * P, dzs + h * vc * P, (vc * P) >> 2);
-        }
-    }
-}
-
-__device__ __forceinline__ int wgrad_vi(const WgradArgs &a, int n) {
-    int vi = a.num_peds ? a.num_peds[n] : a.V;
-    return __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > a.V ? a.V : vi));
-}
-
-template <int CINL>
-__device__ __forceinline__ void wgrad_layer(const WgradArgs &a, int layer, float *buf0, int row_id, int nrows) {
-    constexpr int C = Cfg::C, P = Cfg::P;
-    constexpr int NCOL = 9 * CINL + 1, NTILE = (NCOL + 15) / 16;
-    const int V = a.V, lane = threadIdx.x & 63;
-    const int nq = lane & 15, kq = lane >> 4;
-    const int co_a = nq < P ? nq : P - 1;          // rows 12..15 of the tile are never written back
-    const int pslot = plane_slot(wgrad_image_v(V));
-    const int nch = wgrad_chunks(V), items = a.N * nch;
-    int bcol[NTILE];
-    bool bone[NTILE];
-#pragma unroll
-    for (int tl = 0; tl < NTILE; ++tl) {
-        int col = tl * 16 + nq;
-        bone[tl] = col == NCOL - 1;
-        if (col > NCOL - 2) col = NCOL - 2;
-        bcol[tl] = col;
-    }
-    f32x4 acc[NTILE];
-#pragma unroll
-    for (int tl = 0; tl < NTILE; ++tl) acc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Scenes are dealt round-robin over the layer's waves.  Staging is NOT double-buffered on purpose: two
-    // images per wave halve the residency to one wave per SIMD, and this loop needs two to hide its LDS
-    // latency (measured slower, profiles/); a device-scope scene queue was slower too (dequeue latency).
-    float *cur = buf0;
-    for (int r = 0; r * nrows < items; ++r) {
-        const int it = walk_item(r, row_id, nrows, items, a.order != nullptr && a.serpentine);
-        if (it < 0) continue;
-        const int si = it / nch, chunk = it - si * nch;               // work item = (scene, column chunk)
-        const int n = __builtin_amdgcn_readfirstlane(a.order ? a.order[si] : si);
-        const int vfull = wgrad_vi(a, n);
-        const int nc = wgrad_chunks(vfull);
-        if (vfull == 0 || chunk >= nc) continue;
-        const int wc = (vfull + nc - 1) / nc, w0 = chunk * wc;         // equal chunks
-        const int vi = (vfull - w0) < wc ? (vfull - w0) : wc;          // from here on: the chunk IS the scene
-        if (!STG_SKIP(a, 64)) wgrad_stage<CINL>(a, layer, n, vfull, w0, vi, cur, cur + pslot);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // image of scene n complete
-        __builtin_amdgcn_wave_barrier();
-        const float *plane = cur, *dzs = cur + pslot;
-        const int SW = txp_sw(vi), npos = C * vi;
-        int boff[NTILE];
-#pragma unroll
-        for (int tl = 0; tl < NTILE; ++tl) {
-            const int tap = bcol[tl] / CINL, ci = bcol[tl] - tap * CINL;
-            boff[tl] = ((tap / 3 - 1) * SW + (tap % 3 - 1)) * P + ci;
-        }
-        // K loop over the scene's positions, 4 per MFMA; this lane walks p = kq, kq+4, ...
-        const int nsteps = STG_SKIP(a, 128) ? 0 : (npos + 3) >> 2;
-        const int nfull = vi >= 4 ? (STG_SKIP(a, 128) ? 0 : (npos >> 2)) : 0;   // steps without a K tail
-        int w = kq;                                  // vi >= 4 on the fast path: h = 0
-        int pos_off = (SW + 1 + kq) * P;             // ((h+1)*SW + (w+1)) * P
-        int a_idx = kq * P + co_a;                   // dz is position-major [pos][P]
-        auto advance = [&]() {                       // p += 4 (vi >= 4: at most one row wrap)
-            w += 4;
-            const bool wrap = w >= vi;
-            w -= wrap ? vi : 0;
-            pos_off += wrap ? 6 * P : 4 * P;         // a wrap skips the two border columns (SW = vi + 2)
-            a_idx += 4 * P;
-        };
-        int s = 0;
-        for (; s + 2 <= nfull; s += 2) {
-            float av0 = dzs[a_idx], raw0[NTILE];
-#pragma unroll
-            for (int tl = 0; tl < NTILE; ++tl) raw0[tl] = plane[boff[tl] + pos_off];
-            advance();
-            float av1 = dzs[a_idx], raw1[NTILE];
-#pragma unroll
-            for (int tl = 0; tl < NTILE; ++tl) raw1[tl] = plane[boff[tl] + pos_off];
-            advance();
-#pragma unroll
-            for (int tl = 0; tl < NTILE; ++tl)
-                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bone[tl] ? 1.f : raw0[tl], acc[tl], 0, 0, 0);
-#pragma unroll
-            for (int tl = 0; tl < NTILE; ++tl)
-                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bone[tl] ? 1.f : raw1[tl], acc[tl], 0, 0, 0);
-        }
-        // remaining steps (odd count, K tail p >= npos, or tiny scenes with vi < 4): checked, generic
-        for (; s < nsteps; ++s) {
-            const int p = 4 * s + kq;
-            const bool ok = p < npos;
-            const int pc = ok ? p : 0;
-            const int hh = pc / vi, ww = pc - hh * vi;
-            const float av = ok ? dzs[pc * P + co_a] : 0.f;
-            const int offb = ((hh + 1) * SW + (ww + 1)) * P;
-#pragma unroll
-            for (int tl = 0; tl < NTILE; ++tl) {
-                const float raw = plane[boff[tl] + offb];
-                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bone[tl] ? 1.f : raw, acc[tl], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    // each wave parks its accumulator tiles in its own LDS image as one row [P][CINL][9] weights + [P] biases
-    // (the parameters' own order); the workgroup then sums its waves' rows into ONE slab row
-    float *row = buf0;
-    if (kq < 3) {
-#pragma unroll
-        for (int tl = 0; tl < NTILE; ++tl) {
-            const int col = tl * 16 + nq;
-            if (col < NCOL) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = 4 * kq + r;
-                    if (col == NCOL - 1) {
-                        row[P * CINL * 9 + co] = acc[tl][r];
-                    } else {
-                        const int tap = col / CINL, ci = col - tap * CINL;
-                        row[(co * CINL + ci) * 9 + tap] = acc[tl][r];
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void txp_wgrad_kernel(const WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int wave = threadIdx.x >> 6;
-    const int image = wgrad_image_floats(a.V);                 // one staged scene (plane + dz), >= one slab row
-    float *buf0 = sm + wave * image;
-    // blockIdx.x -> (layer, workgroup within the layer): layer l owns blocks [wg_begin[l], wg_begin[l+1])
-    int layer = 0;
-    while (layer < a.lay.L && (int)blockIdx.x >= a.wg_begin[layer + 1]) ++layer;
-    const int wg = (int)blockIdx.x - a.wg_begin[layer];
-    const int row_id = wg * WAVES + wave;                                           // this wave's scene lane
-    const int nrows = (a.wg_begin[layer + 1] - a.wg_begin[layer]) * WAVES;          // waves of this layer
-    if (layer == 0)
-        wgrad_layer<Cfg::T>(a, layer, buf0, row_id, nrows);
-    else
-        wgrad_layer<Cfg::P>(a, layer, buf0, row_id, nrows);
-    __syncthreads();
-    // slab row of the workgroup = sum of its waves' rows, fixed order
-    const int len = wgrad_row_len(layer);
-    float *dst = a.slab2 + wgrad_slab_base(layer, a.rows) + (int64_t)wg * len;
-    for (int e = threadIdx.x; e < len; e += WAVES * 64) {
-        float t = 0.f;
-#pragma unroll
-        for (int w2 = 0; w2 < WAVES; ++w2) t += sm[w2 * image + e];
-        dst[e] = t;
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -617,49 +356,10 @@ static int bwd_grid_small(const ModelLayout &L, int N, int V) {
     return V > kBwdTierV ? bwd_grid_w(L, N, kBwdTierV, 1) : 0;
 }
 
-// K2 launch geometry: one persistent workgroup of `waves` waves per CU slot; the chip's slots are split
-// over the layers in proportion to their MFMA work (layer 0 has 5 column tiles, the others 7)
-struct WgradGeom {
-    int waves, grid, rows;          // rows = slab rows per layer (max workgroups of a layer * waves)
-    int wg_begin[kMaxTxp + 2];
-    size_t lds;
-};
-static bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
-    const size_t per_wave = (size_t)wgrad_image_floats(V) * sizeof(float);
-    if (per_wave > (size_t)kLdsBytes) return false;
-    int waves = env_waves("STG_WGRAD_WAVES", 8);
-    while (waves > 1 && per_wave * waves > (size_t)kLdsBytes) waves >>= 1;
-    g->waves = waves;
-    g->lds = per_wave * waves;
-    int per_cu = (int)(kLdsBytes / g->lds);
-    const int max_waves = diag_env("STG_WGRAD_MAXW", 8);       // resident waves per CU
-    if (per_cu * waves > max_waves) per_cu = max_waves / waves > 0 ? max_waves / waves : 1;
-    if (per_cu < 1) per_cu = 1;
-    int total = kNumCU * per_cu;                       // resident workgroups on the chip
-    if (const int v = diag_env("STG_WGRAD_GRID", 0)) total = v > 0 ? v : total;
-    const int nl = L.L + 1;
-    if (total < nl) total = nl;
-    const int need = (N * wgrad_chunks(V) + waves - 1) / waves;   // never more workgroups per layer than items need
-    const int wsum = 6 + 7 * (nl - 1);      // per item: same staging bytes, 5 vs 7 column tiles of MFMAs
-    int begin = 0, maxw = 0;
-    for (int l = 0; l < nl; ++l) {
-        int cnt = (int)((int64_t)total * (l == 0 ? 6 : 7) / wsum);
-        if (cnt < 1) cnt = 1;
-        if (cnt > need) cnt = need;
-        g->wg_begin[l] = begin;
-        begin += cnt;
-        if (cnt > maxw) maxw = cnt;
-    }
-    g->wg_begin[nl] = begin;
-    g->grid = begin;
-    g->rows = maxw;                                    // one slab row per workgroup
-    return true;
-}
-
 // scratch carve of stg_model_bwd (offsets in floats):
 //   rows   small-parameter gradient rows [n_rows][n_blk_params + n_txp]: one per persistent workgroup of K1 (both
 //          launches of a two-tier ragged run), or one per SCENE on the wave-per-scene path
-//   slab2  weight-gradient slab rows of K2          dzg  dz_l hand-off [N][L][dz_slot(V)]
+//   slab2  weight-gradient slab rows of K2          dzg  dz_l hand-off [N][L+1][dz_slot(V)]
 //   order  sorted scene list + tier offsets (int32)
 struct BwdCarve {
     int64_t rows, slab2, dzg, order, total;
@@ -679,7 +379,7 @@ static bool bwd_carve(const ModelLayout &L, int N, int V, BwdCarve *c, WgradGeom
         if (!wgrad_geom(L, N, V, wg)) return false;
         fl = (fl + wgrad_slab_base(L.L + 1, wg->rows) + 3) & ~(int64_t)3;
         c->dzg = fl;
-        fl = (fl + (int64_t)N * L.L * dz_slot(V) + 3) & ~(int64_t)3;
+        fl = (fl + (int64_t)N * (L.L + 1) * dz_slot(V) + 3) & ~(int64_t)3;
     }
     c->order = fl;
     c->total = fl + order_floats(N, V);
@@ -743,7 +443,8 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     a.dy = dy; a.ws = ws; a.ws_stride = ws_floats_per_scene(L, V); a.slab1 = rows; a.dzg = dzg; a.dx = dx;
     // ragged batch: sorted scene list at the tail of the scratch buffer
     int32_t *order = reinterpret_cast<int32_t *>(scratch + cv.order);
-    const bool sorted = launch_scene_order(num_peds, N, V, order, order + N, st);
+    int32_t *order_peds = order + N + V + 2;
+    const bool sorted = launch_scene_order(num_peds, N, V, order, order + N, st, order_peds);
     const int serp = diag_env("STG_WALK", 1);
     a.tier = SceneTier{sorted ? order : nullptr, sorted ? order + N : nullptr, -1, V, serp};
     a.debug_skip = diag_env("STG_DEBUG_SKIP", 0);
@@ -758,6 +459,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         t.Vl = V;
         t.debug_skip = a.debug_skip;
         t.split_bf16 = (L.flags & STG_OPT_SPLIT_BF16) ? 1 : 0;
+        t.stagger = diag_env("STG_STAGGER_B", 0);
         const int rcw = launch_txp_bwd_wave(t, st);
         if (rcw != STG_OK) return rcw;
         slab_rows = N;
@@ -820,26 +522,13 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     if (L.n_txp > 0) {
         r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, slab_rows, n_small, cv.rows + (int64_t)L.n_blk_params};
         WgradArgs w{};
-        w.lay = L; w.num_peds = num_peds; w.order = a.tier.order; w.serpentine = a.tier.serpentine; w.N = N; w.V = V; w.dy = dy; w.ws = ws; w.dzg = dzg;
-        w.ws_stride = a.ws_stride; w.slab2 = slab2; w.rows = wg.rows; w.debug_skip = a.debug_skip;
+        w.lay = L; w.num_peds = num_peds; w.order = a.tier.order; w.order_peds = sorted ? order_peds : nullptr;
+        w.serpentine = a.tier.serpentine; w.N = N; w.V = V;
+        w.ws = ws; w.dzg = dzg; w.ws_stride = a.ws_stride; w.slab2 = slab2; w.rows = wg.rows; w.debug_skip = a.debug_skip;
         for (int l = 0; l <= L.L + 1; ++l) w.wg_begin[l] = wg.wg_begin[l];
         if (!STG_SKIP(a, 1)) {
-            const dim3 g2(wg.grid);
-#define STG_LAUNCH_WG(W)                                                                                     \
-    do {                                                                                                     \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_wgrad_kernel<W>),            \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg.lds);        \
-        if (e_ != hipSuccess) return hip_fail(e_, "stg_model_bwd: hipFuncSetAttribute (wgrad)");             \
-        hipLaunchKernelGGL(txp_wgrad_kernel<W>, g2, dim3(W * 64), wg.lds, st, w);                            \
-    } while (0)
-            switch (wg.waves) {
-                case 1: STG_LAUNCH_WG(1); break;
-                case 2: STG_LAUNCH_WG(2); break;
-                case 4: STG_LAUNCH_WG(4); break;
-                default: STG_LAUNCH_WG(8); break;
-            }
-#undef STG_LAUNCH_WG
-            STG_LAUNCH_CHECK("stg_model_bwd: K2");
+            const int rck = launch_txp_wgrad(w, wg, st);
+            if (rck != STG_OK) return rck;
         }
         evl.mark();
         for (int l = 0; l <= L.L; ++l) {

@@ -106,10 +106,13 @@ __device__ __forceinline__ void tier_range(const SceneTier &t, int N, int V, int
 constexpr int kOrderMaxN = 65536;      // scene_order_kernel is ONE workgroup: N/1024 scenes per lane
 constexpr int kOrderMaxV = 1023;
 // floats reserved in the scratch buffers for the scene order: N int32 + the V+2 tier offsets key_start[]
-__host__ __device__ inline int64_t order_floats(int N, int V) { return ((int64_t)N + V + 2 + 3) & ~(int64_t)3; }
+// (+ the sorted pedestrian counts behind them: N more)
+__host__ __device__ inline int64_t order_floats(int N, int V) { return ((int64_t)2 * N + V + 2 + 3) & ~(int64_t)3; }
 // Fills order[0..N) with the scene indices sorted by clamp(num_peds[n], 0, V) descending (stable) on `st`;
 // returns false (order untouched) when the batch is outside the kernel's limits or num_peds is null.
-bool launch_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, int32_t *key_start, hipStream_t st);
+// order_peds (optional): order_peds[i] = clamp(num_peds[order[i]], 0, V), the sorted counts themselves.
+bool launch_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, int32_t *key_start, hipStream_t st,
+                        int32_t *order_peds = nullptr);
 
 // stgcn_agg.hip: ax = x A ([cin][T][V_n]) and cs = colsum(A) ([T][V_n]) of every scene -- the one read of A in a
 // step -- written to out + n * out_stride + ax_off / cs_off.

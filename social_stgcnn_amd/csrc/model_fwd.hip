@@ -299,6 +299,7 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         t.tier = SceneTier{sorted ? order : nullptr, sorted ? order + N : nullptr, -1, V, serp};
         t.Vl = V;
         t.debug_skip = a.debug_skip;
+        t.stagger = diag_env("STG_STAGGER_F", 0);
         const int rcw = launch_txp_fwd_wave(t, st);
         evl.mark();
         evl.finish();

@@ -100,7 +100,8 @@ int make_layout(const stg_model_desc *d, ModelLayout *lay) {
 // most x pedestrians are order[key_start[V - x] .. N): the V-tiers of the entry points.
 __global__ __launch_bounds__(1024) void scene_order_kernel(const int32_t *__restrict__ num_peds, int N, int V,
                                                            int32_t *__restrict__ order,
-                                                           int32_t *__restrict__ key_start) {
+                                                           int32_t *__restrict__ key_start,
+                                                           int32_t *__restrict__ order_peds) {
     extern __shared__ int hist[];      // [K][16]
     __shared__ int wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, K = V + 1;
@@ -170,20 +171,22 @@ __global__ __launch_bounds__(1024) void scene_order_kernel(const int32_t *__rest
         if (k >= 0) {
             const int base = hist[k * 16 + wv];
             order[base + rank] = i;
+            if (order_peds) order_peds[base + rank] = V - k;      // the sorted (clamped) pedestrian counts themselves
             __builtin_amdgcn_wave_barrier();
             if (last) hist[k * 16 + wv] = base + rank + 1;
         }
     }
 }
 
-bool launch_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, int32_t *key_start, hipStream_t st) {
+bool launch_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, int32_t *key_start, hipStream_t st,
+                        int32_t *order_peds) {
     if (!num_peds || !order || N < 2 || N > kOrderMaxN || V > kOrderMaxV) return false;
     const size_t lds = (size_t)(V + 1) * 16 * sizeof(int);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(&scene_order_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return false;
-    hipLaunchKernelGGL(scene_order_kernel, dim3(1), dim3(1024), lds, st, num_peds, N, V, order, key_start);
+    hipLaunchKernelGGL(scene_order_kernel, dim3(1), dim3(1024), lds, st, num_peds, N, V, order, key_start, order_peds);
     return hipGetLastError() == hipSuccess;
 }
 

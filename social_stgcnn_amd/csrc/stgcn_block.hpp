@@ -27,8 +27,7 @@ struct Scope {
 // Sum K per-thread values over the scope; every thread holds the totals on return.
 template <int K, int WAVES>
 __device__ __forceinline__ void block_sum(float (&v)[K], float *red) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    wave_sum_n<K>(v);
     if (WAVES > 1) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         __syncthreads();
@@ -53,8 +52,7 @@ __device__ __forceinline__ void block_reduce(float (&v)[K], float *red, float *t
     static_assert(K <= kRedMax, "reduction too wide");
     using S = Scope<WAVES>;
     const int tid = S::tid();
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    wave_sum_n<K>(v);
     if (WAVES == 0) {
         S::sync();
         if (tid == 0) {
@@ -448,6 +446,261 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
         }
     }
     S::sync();
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, COLUMN mode (wave kernels, V_n <= 64): lane w owns pedestrian w and keeps all T time steps of every
+// channel in registers -- the temporal convolution, the residual branch and both BatchNorm applications never touch
+// LDS, and the whole block is ~2k straight-line VALU instructions instead of seven LDS round trips over runtime-trip
+// loops.  Cross-lane traffic: the 30 DPP wave sums of the per-scene BatchNorm statistics, nothing else.
+// The outputs go straight into the zero-bordered TXP plane image (zeroed here first; nothing of the block lives in
+// LDS).  P_ / B_: the block's parameters / running statistics (the workgroup's LDS copy).  First-block shape only:
+// CIN0 input channels, residual = conv + BN (2) or none (0).
+// ------------------------------------------------------------------------------------------
+template <typename Args>
+__device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float *P_, const float *B_, const BlockLayout &b,
+                                                     int n, int vi, float *wsn, float *statn, const float *pre_ax,
+                                                     const float *pre_cs, float *plane, int plane_sc, float *plane_base,
+                                                     int plane_zero_f4, ptab_t *qtab) {
+    constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, CIN = Cfg::CIN0;
+    [[maybe_unused]] constexpr int WAVES = 0;          // (diagnostic stamps)
+    const int w = threadIdx.x & 63, V = a.V;
+    const bool act = w < vi;
+    const float fact = act ? 1.f : 0.f;
+    const int cnt = T * vi;
+    const bool train = a.lay.bn_mode == 1;
+    const float eps = a.lay.eps, inv_cnt = 1.0f / (float)cnt;
+    float *wsa = wsn ? wsn + a.lay.ws_hdr_floats : nullptr;
+    // ---- inputs of pedestrian w: block input x (strided view), aggregated input ax, colsum cs ----------------
+    float x[CIN][T], g[C][T];
+    {
+        float ax[CIN][T], cs[T];
+        const float *xn = a.x + n * a.x_sn + w * a.x_sv;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            cs[t] = act ? pre_cs[t * vi + w] : 0.f;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                ax[ci][t] = act ? pre_ax[(ci * T + t) * vi + w] : 0.f;
+                x[ci][t] = act ? xn[ci * a.x_sc + t * a.x_st] : 0.f;
+            }
+        }
+        // (while those loads are in flight) the TXP plane image: zeros everywhere but the interior this block writes
+        // at the end; the scene's position table
+        {
+            float4 *z4 = reinterpret_cast<float4 *>(plane_base);
+            for (int e = w; e < plane_zero_f4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = w; p < T * vi; p += 64) {
+                const int h = p / vi;
+                qtab[p] = (ptab_t)((h << 8) | (p - h * vi));
+            }
+        }
+        // ---- gcn 1x1 conv on the aggregated input (model.py:66-67) --------------------------------------
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float bg = P_[b.gcn_b + c];
+            float wg[CIN];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) wg[ci] = P_[b.gcn_w + c * CIN + ci];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                float v = bg * cs[t];
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) v = fmaf(wg[ci], ax[ci][t], v);
+                g[c][t] = v;
+                if (wsa && act) wsa[(int64_t)b.ws_g * V + (c * T + t) * vi + w] = v;
+            }
+        }
+    }
+    STG_BLK_STAMP(9);
+    // ---- BatchNorm tcn.0 (per-scene statistics in training) + PReLU ---------------------------------------
+    float m1[C], r1[C];
+    if (train) {
+        float s1[C], s2[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            s1[c] = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) s1[c] += g[c][t];            // (inactive lanes hold zeros)
+        }
+        wave_sum_n<C>(s1);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            m1[c] = s1[c] * inv_cnt;
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float d = g[c][t] - m1[c];
+                s = fmaf(d, d, s);
+            }
+            s2[c] = s * fact;
+        }
+        wave_sum_n<C>(s2);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            r1[c] = 1.0f / sqrtf(s2[c] * inv_cnt + eps);
+            if (statn && w == 0) {
+                statn[b.stat + c] = m1[c];
+                statn[b.stat + C + c] = s2[c] / (float)(cnt - 1);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            m1[c] = B_[b.buf + c];
+            r1[c] = 1.0f / sqrtf(B_[b.buf + C + c] + eps);
+        }
+    }
+    STG_BLK_STAMP(10);
+    {
+        const float al = P_[b.prelu1];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float ga = P_[b.bn1_g + c], be = P_[b.bn1_b + c];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float v = fmaf((g[c][t] - m1[c]) * r1[c], ga, be);
+                g[c][t] = v > 0.f ? v : al * v;                    // h1
+            }
+        }
+    }
+    STG_BLK_STAMP(11);
+    // ---- temporal conv tcn.2 (all taps in this lane's registers) ----------------------------------------
+    float h2[C][T];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float tb = P_[b.tcn_b + c];
+#pragma unroll
+        for (int t = 0; t < T; ++t) h2[c][t] = tb;
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+            for (int dt = 0; dt < KT; ++dt) {
+                const float wv = P_[b.tcn_w + (c * C + ci) * KT + dt];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int ti = t + dt - (KT - 1) / 2;
+                    if (ti >= 0 && ti < T) h2[c][t] = fmaf(wv, g[ci][ti], h2[c][t]);
+                }
+            }
+        if (wsa && act) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) wsa[(int64_t)b.ws_h2 * V + (c * T + t) * vi + w] = h2[c][t];
+        }
+    }
+    STG_BLK_STAMP(12);
+    // ---- BatchNorm tcn.3 / residual.1 statistics ---------------------------------------------------------
+    auto res_val = [&](int c, int t, float rb, const float (&rw)[CIN]) -> float {
+        float r = rb;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) r = fmaf(rw[ci], x[ci][t], r);
+        return r;
+    };
+    float m2[C], r2[C], mr[C], rr[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { mr[c] = 0.f; rr[c] = 0.f; }
+    if (train) {
+        float sm2[2 * C], sv2[2 * C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float s = 0.f, sr = 0.f;
+            float rw[CIN];
+            const float rb = b.residual == 2 ? P_[b.res_b + c] : 0.f;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) rw[ci] = b.residual == 2 ? P_[b.res_w + c * CIN + ci] : 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                s += h2[c][t];
+                if (b.residual == 2) sr += res_val(c, t, rb, rw);
+            }
+            sm2[c] = s * fact;
+            sm2[C + c] = sr * fact;
+        }
+        wave_sum_n<2 * C>(sm2);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            m2[c] = sm2[c] * inv_cnt;
+            mr[c] = b.residual == 2 ? sm2[C + c] * inv_cnt : 0.f;
+            float rw[CIN];
+            const float rb = b.residual == 2 ? P_[b.res_b + c] : 0.f;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) rw[ci] = b.residual == 2 ? P_[b.res_w + c * CIN + ci] : 0.f;
+            float v = 0.f, vr = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float d = h2[c][t] - m2[c];
+                v = fmaf(d, d, v);
+                if (b.residual == 2) {
+                    const float dr = res_val(c, t, rb, rw) - mr[c];
+                    vr = fmaf(dr, dr, vr);
+                }
+            }
+            sv2[c] = v * fact;
+            sv2[C + c] = vr * fact;
+        }
+        wave_sum_n<2 * C>(sv2);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            r2[c] = 1.0f / sqrtf(sv2[c] * inv_cnt + eps);
+            rr[c] = 1.0f / sqrtf((b.residual == 2 ? sv2[C + c] * inv_cnt : 0.f) + eps);
+            if (statn && w == 0) {
+                statn[b.stat + 2 * C + c] = m2[c];
+                statn[b.stat + 3 * C + c] = sv2[c] / (float)(cnt - 1);
+                if (b.residual == 2) {
+                    statn[b.stat + 4 * C + c] = mr[c];
+                    statn[b.stat + 5 * C + c] = sv2[C + c] / (float)(cnt - 1);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            m2[c] = B_[b.buf + 2 * C + c];
+            r2[c] = 1.0f / sqrtf(B_[b.buf + 3 * C + c] + eps);
+            if (b.residual == 2) {
+                mr[c] = B_[b.buf + 4 * C + c];
+                rr[c] = 1.0f / sqrtf(B_[b.buf + 5 * C + c] + eps);
+            }
+        }
+    }
+    STG_BLK_STAMP(13);
+    if (wsn && w == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            wsn[b.ws_hdr + c] = m1[c];
+            wsn[b.ws_hdr + C + c] = r1[c];
+            wsn[b.ws_hdr + 2 * C + c] = m2[c];
+            wsn[b.ws_hdr + 3 * C + c] = r2[c];
+            wsn[b.ws_hdr + 4 * C + c] = mr[c];
+            wsn[b.ws_hdr + 5 * C + c] = rr[c];
+        }
+    }
+    STG_BLK_STAMP(14);
+    // ---- BN (tcn.3) + residual + PReLU (model.py:150-153) -> the TXP plane -------------------------------
+    __builtin_amdgcn_wave_barrier();                  // (the image is zero before its interior is written)
+    const float ao = P_[b.prelu_o];
+    const int SW = txp_sw(vi);
+    float *pw = plane + (w + 1);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float g2 = P_[b.bn2_g + c], b2 = P_[b.bn2_b + c];
+        float rw[CIN];
+        const float rb = b.residual == 2 ? P_[b.res_b + c] : 0.f;
+        const float gr = b.residual == 2 ? P_[b.bnr_g + c] : 0.f, br = b.residual == 2 ? P_[b.bnr_b + c] : 0.f;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) rw[ci] = b.residual == 2 ? P_[b.res_w + c * CIN + ci] : 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float u = fmaf((h2[c][t] - m2[c]) * r2[c], g2, b2);
+            if (b.residual == 2) u += fmaf((res_val(c, t, rb, rw) - mr[c]) * rr[c], gr, br);
+            const float s = (a.lay.use_mdn || u > 0.f) ? u : ao * u;
+            // v.view(N, T, C, V) (model.py:187): flat plane index f = c*T+t -> (f / C, f % C), static here
+            constexpr int dummy = 0; (void)dummy;
+            const int f = c * T + t, ch = f / C, row = f - ch * C;
+            if (act) pw[ch * plane_sc + (row + 1) * SW] = s;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // ------------------------------------------------------------------------------------------

@@ -303,19 +303,25 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, const float *
 
     // ---- st_gcn block (model.py:145-155) ------------------------------------------------------------
     {
-        float *G = buf, *X = buf + C * T * vi, *H = buf + P * SC - C * T * vi;
-        const float *xn = a.x + n * a.x_sn;
-        for (int e = lane; e < Cfg::CIN0 * T * vi; e += 64) {      // strided: the caller's permute(0,3,1,2) view
-            const int v = e % vi, ct = e / vi, t = ct % T, c = ct / T;
-            X[e] = xn[c * a.x_sc + t * a.x_st + v * a.x_sv];
-        }
-        build_ptab(ptab, vi);
-        __builtin_amdgcn_wave_barrier();
-        STG_STAMP(9);
         const float *agn = a.agg + n * a.agg_stride;
-        stgcn_block_fwd<Cfg::CIN0, 0>(a, blk_params, blk_buffers, L.blk[0], n, vi, X, G, H, nullptr, wsn, statn,
-                                      agn + a.agg_ax, agn + a.agg_cs, true, buf + 2 * SW, SC, buf, (P * SC) >> 2,
-                                      nullptr, false, ptab);
+        if (vi <= 64 && !STG_SKIP(a, 256)) {
+            // column mode: lane = pedestrian, everything in registers, outputs straight into the plane image
+            stgcn_block_fwd_cols(a, blk_params, blk_buffers, L.blk[0], n, vi, wsn, statn, agn + a.agg_ax, agn + a.agg_cs,
+                                 buf + 2 * SW, SC, buf, (P * SC) >> 2, ptab);
+        } else {
+            build_ptab(ptab, vi);
+            float *G = buf, *X = buf + C * T * vi, *H = buf + P * SC - C * T * vi;
+            const float *xn = a.x + n * a.x_sn;
+            for (int e = lane; e < Cfg::CIN0 * T * vi; e += 64) {      // strided: the caller's permute(0,3,1,2) view
+                const int v = e % vi, ct = e / vi, t = ct % T, c = ct / T;
+                X[e] = xn[c * a.x_sc + t * a.x_st + v * a.x_sv];
+            }
+            __builtin_amdgcn_wave_barrier();
+            STG_STAMP(9);
+            stgcn_block_fwd<Cfg::CIN0, 0>(a, blk_params, blk_buffers, L.blk[0], n, vi, X, G, H, nullptr, wsn, statn,
+                                          agn + a.agg_ax, agn + a.agg_cs, true, buf + 2 * SW, SC, buf, (P * SC) >> 2,
+                                          nullptr, false, ptab);
+        }
     }
     STG_STAMP(1);
     // a_0 now sits in the in-place layout (T channels, rows at slot offset 2, zeros elsewhere)
@@ -405,6 +411,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
     ptab_t *ptab = reinterpret_cast<ptab_t *>(pa + slot);
     float *blk_p = sm + WPB * per_wave, *blk_b = blk_p + ((a.lay.n_blk_params + 3) & ~3);
     stage_block_params(a.lay, params, buffers, blk_p, blk_b, WPB * 64);
+    stagger_start(wave, WPB, a.stagger);
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;
     int begin, end;
     tier_range(a.tier, a.N, a.V, begin, end);
@@ -487,6 +494,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, const float *
         float slope_acc = 0.f;
         if (STG_SKIP(a, 512)) {
         } else if (is_out) {
+            float *dzo_out = a.dzg + ((int64_t)n * (L.L + 1) + L.L) * dz_slot(V);
             // dz of the output conv is dy: (C*P) rows of V floats, vi valid -> plane interior.  Lanes are laid over
             // (sub-row, w) with the row length rounded up to a power of two: no division by the runtime vi
             // (it cost ~50 instructions per element, 30 elements per lane)
@@ -512,11 +520,20 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, const float *
                         if (li[u] >= 0) dzb[li[u]] = dv[u];
                 }
             }
+            // position-major copy of this dz (= dy) for the weight-gradient GEMM: one 16-byte store per (position,
+            // channel quad), gathered from the plane just built
+            __builtin_amdgcn_wave_barrier();
+            for (int vv = lane; vv < (P * npos) >> 2; vv += 64) {
+                const int p = vv / 3, q = vv - p * 3;
+                const unsigned hw = ptab[p];
+                const float *src = dzb + (4 * q) * SC + ((int)(hw >> 8) + 1) * SW + ((int)(hw & 0xffu) + 1);
+                reinterpret_cast<f32x4 *>(dzo_out)[vv] = f32x4{src[0], src[SC], src[2 * SC], src[3 * SC]};
+            }
         } else {
             // dz_l = d(a_{l+1}) * prelu'(z_l); z is position-major [pos][12]; dz also leaves for the
             // weight-gradient GEMM, position-major as well (one 16-byte store per lane)
             const float *zl = wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V;
-            float *dzo = a.dzg + ((int64_t)n * L.L + l) * dz_slot(V);
+            float *dzo = a.dzg + ((int64_t)n * (L.L + 1) + l) * dz_slot(V);
             const float alpha = Pm[L.prelus + l];
             // z_l is position-major [pos][12]: 3 x 16 bytes per position; 8 vectors in flight per lane so the
             // HBM latency is paid once per layer, not once per element batch
@@ -684,6 +701,7 @@ __device__ __forceinline__ void txp_bwd_scene_bf16(const TxpBwdArgs &a, const fl
         const bool is_out = l == L.L;
         float slope_acc = 0.f;
         if (is_out) {
+            float *dzo_out = a.dzg + ((int64_t)n * (L.L + 1) + L.L) * dz_slot(V);
             // dz of the output conv is dy: (C*P) rows of V floats, vi valid -> split, position-major plane interior
             constexpr int U = 4;
             const int vp = vi <= 1 ? 1 : (vi <= 2 ? 2 : (vi <= 4 ? 4 : (vi <= 8 ? 8 : (vi <= 16 ? 16 : (vi <= 32 ? 32 : 64)))));
@@ -694,18 +712,20 @@ __device__ __forceinline__ void txp_bwd_scene_bf16(const TxpBwdArgs &a, const fl
                 const bool okw = w < vi;
                 for (int r0 = 0; r0 < C * P; r0 += rpi * U) {
                     float dv[U];
-                    int bo[U];
+                    int bo[U], gi[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int row = r0 + u * rpi + sub;
                         const bool ok = okw && row < C * P;
                         const int rc = ok ? row : 0, ch = rc / C, h = rc - ch * C;
                         bo[u] = ok ? ((h + 1) * SW + (w + 1)) * 24 + ch * 2 : -1;
+                        gi[u] = (h * vi + w) * P + ch;
                         dv[u] = ok ? dyn[(int64_t)rc * V + w] : 0.f;
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u)
                         if (bo[u] >= 0) {
+                            dzo_out[gi[u]] = dv[u];          // position-major copy for the weight-gradient GEMM
                             const unsigned short h16 = bf16_rne(dv[u]);
                             *reinterpret_cast<unsigned short *>(hi + bo[u]) = h16;
                             *reinterpret_cast<unsigned short *>(lo + bo[u]) = bf16_rne(dv[u] - bf16_val(h16));
@@ -714,7 +734,7 @@ __device__ __forceinline__ void txp_bwd_scene_bf16(const TxpBwdArgs &a, const fl
             }
         } else {
             const float *zl = wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V;
-            float *dzo = a.dzg + ((int64_t)n * L.L + l) * dz_slot(V);
+            float *dzo = a.dzg + ((int64_t)n * (L.L + 1) + l) * dz_slot(V);
             const float alpha = Pm[L.prelus + l];
             constexpr int UV = 8;
             const int nvec = (P * npos) >> 2;
@@ -784,6 +804,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) void txp_bwd_wave_kerne
     float *tot = dcur + P * C * Vl + ptab_floats(Vl);
     float *blk_p = sm + WPB * per_wave;
     stage_block_params(a.lay, a.params, nullptr, blk_p, nullptr, WPB * 64);
+    stagger_start(wave, WPB, a.stagger);
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;
     int begin, end;
     tier_range(a.tier, a.N, a.V, begin, end);

@@ -36,6 +36,7 @@ struct TxpFwdArgs {
     float *stats;          // (N, stat_floats) per-scene BatchNorm statistics (bn_mode 1) or null
     unsigned long long *stamps;   // diagnostic build only (STG_STAMPS=1): [N][16] s_memtime stamps, else null
     int debug_skip;        // diagnostic builds only
+    int stagger;           // start delay of the second half of every workgroup's waves (stagger_start units)
 };
 
 // backward: TXP-CNN input-gradient chain + the st_gcn block backward per scene (everything but the TXP weight gradients)
@@ -58,6 +59,7 @@ struct TxpBwdArgs {
     float *rows;           // [N][n_blk_params + n_txp]  per-scene small-parameter gradients: st_gcn block, PReLU slopes
     int debug_skip;        // timing-only diagnostic (STG_DEBUG_SKIP): 512 dz build, 1024 dgrad tile loops -- wrong results
     int split_bf16;        // 1: the input-gradient GEMMs run on bf16 MFMAs with hi/lo-split operands (see txp_wave.hip)
+    int stagger;           // start delay of the second half of every workgroup's waves (stagger_start units)
 };
 
 // true when the wave-per-scene path serves this model / V (else the workgroup-per-scene kernels run)

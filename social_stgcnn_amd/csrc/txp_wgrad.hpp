@@ -1,0 +1,50 @@
+// txp_wgrad (K2): the TXP-CNN weight / bias gradients -- argument block, launch geometry, launcher.
+#pragma once
+#include "model_common.hpp"
+
+namespace stg {
+
+// K2 stages at most kWgradChunkV pedestrian columns of a scene at a time: a larger scene is cut into
+// ceil(V_n / kWgradChunkV) equal column chunks (each with its two halo columns of the plane), every chunk one work item
+// whose LDS image -- and K loop -- is that of a small scene.  The weight gradient is a sum over positions, so chunks add.
+constexpr int kWgradChunkV = 32;
+__host__ __device__ inline int wgrad_chunks(int V) { return (V + kWgradChunkV - 1) / kWgradChunkV; }
+__host__ __device__ inline int wgrad_image_v(int V) { return V < kWgradChunkV ? V : kWgradChunkV; }
+// floats of one staged work item: the zero-bordered position-major plane a_l + dz_l
+__host__ __device__ inline int wgrad_image_floats(int V0) {
+    const int V = wgrad_image_v(V0);
+    return plane_slot(V) + dz_slot(V);
+}
+// slab geometry: layer 0 has c_in = T, layers 1..L (L = output conv) have c_in = P; one row = [P][c_in][9] + [P]
+__host__ __device__ inline int wgrad_row_len(int layer) {
+    return Cfg::P * (layer == 0 ? Cfg::T : Cfg::P) * 9 + Cfg::P;
+}
+__host__ __device__ inline int64_t wgrad_slab_base(int layer, int rows) {
+    return layer == 0 ? 0 : (int64_t)rows * (wgrad_row_len(0) + (int64_t)(layer - 1) * wgrad_row_len(1));
+}
+
+struct WgradGeom {
+    int waves, nbuf, grid, rows;    // rows = slab rows per layer (= the largest workgroup count of a layer)
+    int wg_begin[kMaxTxp + 2];      // layer l owns workgroups [wg_begin[l], wg_begin[l+1])
+    size_t lds;
+};
+bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g);
+
+struct WgradArgs {
+    ModelLayout lay;
+    const int32_t *num_peds;
+    const int32_t *order;  // non-null: scenes sorted by crowd size (descending)
+    const int32_t *order_peds;   // with `order`: order_peds[i] = pedestrians of scene order[i] (clamped to [0, V])
+    int serpentine;        // walk the sorted list boustrophedon (1) or with a plain stride (0)
+    int N, V;
+    const float *ws;       // saved planes a_0 .. a_L (position-major, interior rows with their border columns)
+    const float *dzg;      // [N][L+1][dz_slot(V)]  dz_l of every layer (l = L: the output conv's, i.e. dy), position-major
+    int64_t ws_stride;
+    float *slab2;          // [layer 0..L][rows][row_len(layer)] packed, see wgrad_slab_base()
+    int rows;
+    int wg_begin[kMaxTxp + 2];
+    int debug_skip;        // diagnostic builds only: 64 skip staging, 128 skip the MFMA loop
+};
+int launch_txp_wgrad(const WgradArgs &w, const WgradGeom &g, hipStream_t st);
+
+}  // namespace stg

@@ -41,7 +41,7 @@ print("scene total  median %d cycles; start spread: p50 %d p90 %d max %d" % (np.
 # st_gcn block phases (stamps 9..14 inside stgcn_block_fwd, wave mode)
 if st[:, 14].max() > 0:
     cols = [0, 9, 10, 11, 12, 13, 14, 1]
-    nm = ["x stage+ptab", "P1 g=W ax", "BN1 stats", "P3 bn+prelu", "P4 tconv", "BN2 stats", "P6+zero+scatter"]
+    nm = ["ptab+loads+g", "BN1 stats", "bn+prelu", "tconv+save", "BN2/BNr stats", "header", "output->plane"]
     for k in range(7):
         d_ = st[:, cols[k + 1]] - st[:, cols[k]]
         print("  %-16s median %7d  p10 %7d  p90 %7d cycles" % (nm[k], np.median(d_), np.percentile(d_, 10), np.percentile(d_, 90)))
