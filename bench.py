@@ -4,27 +4,35 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch of synthetic scene-windows already resident in
-HBM: model forward (st_gcn + TXP-CNN) -> bivariate NLL -> backward -> [gradient all-reduce over
-RCCL when N > 1] -> SGD update.  Workload (BASELINE.json north-star): obs 8 / pred 12, V = 32
-pedestrians, 2048 scene-windows per GPU, fp32; synthetic trajectories per SURVEY 8d (random-walk
-recipe of complete_nuscenes_setup.py:264-286), random-init weights (torch.manual_seed(0)).
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself, as child processes,
+before anything touches the GPU; rank 0's JSON line is the output and a failing rank fails the run.
+
+A "step" is one pass of the hot path over one batch of scene-windows already resident in HBM: adjacency-weighted
+aggregation -> st_gcn block + TXP-CNN -> bivariate NLL -> backward -> [ONE all-reduce over RCCL when N > 1] -> SGD
+update, replayed as a hipGraph.  Workload (BASELINE.json north-star): obs 8 / pred 12, V = 32 pedestrians, 2048
+scene-windows per GPU, fp32; synthetic trajectories per SURVEY 8d (random-walk recipe of
+complete_nuscenes_setup.py:264-286), random-init weights (torch.manual_seed(0)).  `--dataset eth-train --batch 512` is
+BASELINE configs[1] on the real (ragged) eth/train windows that travel with the repo as a test fixture.
+
+Timing: W warm-up steps, then R blocks of EXACTLY K steps, each block bracketed by barrier + torch.cuda.synchronize()
+on both sides (MAX over ranks); `ms_per_step` / `value` are the MEDIAN block, p10 / p90 ride along (R is chosen so the
+timed region lasts >= 1 s).  Two different input batches alternate from step to step.
 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
-  roofline     the backward entry point (its kernels) algorithmic FLOP/s vs the fp32 MFMA/vector peak,
-               timed with HIP events on the launch stream inside the timed region,
-  cpu_baseline the CPU oracle run the way the reference runs (one scene per forward, N = 1) on a
-               bounded sample of the same workload, rank 0 / N = 1 only,
-  kernels      stand-alone adj_build / spatial_agg HBM GB/s (the north-star's bandwidth kernels).
+  roofline     the DOMINANT SINGLE KERNEL of the step: algorithmic FLOP per launch / its mean duration, measured live
+               with HIP events the library records between its kernels on the launch stream (`composite` = the whole
+               backward entry point as last round),
+  pipeline     the same step with the adjacency build (utils.seq_to_graph as a HIP kernel) inside the graph,
+  kernels      stand-alone HBM kernels on a working set beyond the 256 MiB Infinity Cache,
+  cpu_baseline the CPU oracle run the way the reference runs (one scene per forward, N = 1) on a bounded sample of the
+               same workload: 1 thread, plus `cpu_baseline_all_cores` (one single-threaded worker per core).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -35,9 +43,60 @@ PEAK_FP32_TFLOPS = 157.3      # MI355X fp32 vector == fp32-input MFMA dense peak
 PEAK_HBM_GBS = 8000.0
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=0, help="timed blocks of --steps steps (0: >= 30 and >= 1 s)")
+    ap.add_argument("--batch", type=int, default=2048, help="scene-windows per GPU")
+    ap.add_argument("--peds", type=int, default=32, help="pedestrians per scene-window (V)")
+    ap.add_argument("--ragged", choices=("shuffled", "sorted"), default=None,
+                    help="ragged batch: pedestrians per scene drawn from the eth/train histogram (padded to the "
+                         "largest draw); 'sorted' orders the scenes by crowd size")
+    ap.add_argument("--dataset", choices=("synthetic", "eth-train"), default="synthetic",
+                    help="eth-train: real ragged windows of tests/golden/data/eth_train (BASELINE configs[1])")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="bf16: bf16 STORAGE of saved activations / hand-offs (fp32 accumulate, fp32 parameters)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-extras", action="store_true", help="skip the pipeline / stand-alone kernel / roofline legs")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------
+# self-launch: N ranks as child processes, before this process touches the GPU
+# ------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+        raise SystemExit(1)
+    sys.stdout.write(out0)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------
+# workload
+# ------------------------------------------------------------------------------------------
 def synth_scenes(n, v, seed):
     """start ~ U(-10,10)^2, velocity ~ U(-.5,.5)^2, position noise N(0,.1), velocity noise
     N(0,.05) clipped to +-1, rounded to 4 decimals; rel = first difference with rel[0] = 0."""
+    import numpy as np
     rng = np.random.default_rng(seed)
     t_all = T_OBS + T_PRED
     pos = rng.uniform(-10, 10, (n, v, 2))
@@ -64,12 +123,29 @@ ETH_TRAIN_PEDS_HIST = [0, 0, 559, 371, 319, 226, 163, 117, 84, 84, 46, 27, 24, 3
 
 
 def ragged_counts(n, seed, order="shuffled"):
-    """n pedestrian counts drawn from the eth/train histogram (BASELINE configs[1]: 'ETH train, batch=512')."""
+    """n pedestrian counts drawn from the eth/train histogram."""
+    import numpy as np
     h = np.asarray(ETH_TRAIN_PEDS_HIST, dtype=np.float64)
     c = np.random.default_rng(seed).choice(len(h), size=n, p=h / h.sum()).astype(np.int32)
     if order == "sorted":
         c = np.sort(c)[::-1].copy()
     return c
+
+
+def eth_train_batches(n, n_batches, seed):
+    """n_batches batches of n real eth/train windows (seeded shuffle of the 2,785 windows, like the reference's
+    DataLoader(shuffle=True)), each padded to ITS largest crowd: (obs_rel (N,V,2,8), target (N,P,V,2), counts)."""
+    import numpy as np
+    from social_stgcnn_amd import data
+    win = data.load_windows(os.path.join(ROOT, "tests", "golden", "data", "eth_train"), T_OBS, T_PRED, 1,
+                            with_non_linear=False)
+    perm = np.random.default_rng(seed).permutation(len(win))
+    out = []
+    for b in range(n_batches):
+        idx = np.sort(perm[(b * n) % len(win):][:n]) if (b * n) % len(win) + n <= len(win) else np.sort(perm[:n])
+        obs_rel, pred_rel, _, _, counts = data.pad_batch(win, idx)
+        out.append((np.ascontiguousarray(np.transpose(obs_rel, (0, 2, 3, 1))), pred_rel, counts))
+    return out, len(win)
 
 
 def flops_per_window(v, fwd=True, bwd=True):
@@ -83,7 +159,20 @@ def bytes_per_window(v):
     return 608 * v + 64 * v * v
 
 
-def time_kernel(fn, iters=20, warm=3):
+# algorithmic FLOP per scene-window of the kernels behind the fused entry points, in launch order (SURVEY 8d split:
+# TXP convs 60,480 V forward, the same again for the input gradients and for the weight gradients; gcn/tcn/residual
+# convs 1,520 V; the aggregation 80 V^2 with its 2x re-association saving not credited)
+KERNELS = {
+    "model_fwd": [("stgcn_agg_kernel (x A, colsum A: the read of A)", lambda v: 80 * v * v, "hbm"),
+                  ("txp_fwd_wave_kernel (st_gcn block + TXP-CNN forward)", lambda v: 62000 * v, "mfma")],
+    "model_bwd": [("txp_bwd_wave_kernel (TXP input-gradient chain + st_gcn block backward)",
+                   lambda v: 60480 * v + 2 * 1520 * v + 80 * v * v, "mfma"),
+                  ("txp_wgrad_kernel (TXP weight / bias gradients)", lambda v: 60480 * v, "mfma"),
+                  ("reduce_slabs_kernel", lambda v: 0, "hbm")],
+}
+
+
+def time_kernel(torch, fn, iters=10, warm=2):
     for _ in range(warm):
         fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -95,19 +184,24 @@ def time_kernel(fn, iters=20, warm=3):
     return a.elapsed_time(b) / iters
 
 
-def cpu_baseline(obs_rel, target, budget_s=15.0, counts=None):
-    """The oracle, driven like train.py:36-77 drives the reference: one scene per forward (N = 1),
-    loss, backward -- single thread, bounded sample of the same workload."""
+# ------------------------------------------------------------------------------------------
+# CPU baseline: the oracle, driven like train.py:36-77 drives the reference
+# ------------------------------------------------------------------------------------------
+def cpu_worker_loop(v, budget_s, seed, counts=None):
+    """one single-threaded worker: oracle forward + loss + backward, one scene per forward, for budget_s seconds"""
+    import numpy as np
+    import torch
     from oracle import stgcnn_oracle as O
+    from social_stgcnn_amd.model import social_stgcnn
     torch.set_num_threads(1)
     torch.manual_seed(0)
-    from social_stgcnn_amd.model import social_stgcnn
+    obs_rel, target = synth_scenes(32, v, seed)
     m = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3, pred_seq_len=12)
-    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    state = {k: t.detach().clone() for k, t in m.state_dict().items()}
     keys = [k for k, _ in m.named_parameters()]
     scenes = []
-    for i in range(min(64, obs_rel.shape[0])):
-        c = obs_rel.shape[1] if counts is None else int(counts[i])
+    for i in range(obs_rel.shape[0]):
+        c = v if counts is None else max(1, int(counts[i % len(counts)]))
         nodes, lap = O.seq_to_graph_np(obs_rel[i, :c])
         scenes.append((torch.from_numpy(nodes).unsqueeze(0).permute(0, 3, 1, 2), torch.from_numpy(lap),
                        torch.from_numpy(np.ascontiguousarray(target[i, :, :c]))))
@@ -120,54 +214,57 @@ def cpu_baseline(obs_rel, target, budget_s=15.0, counts=None):
         loss, _ = O.scene_loss(work, x, a, tgt, True)
         loss.backward()
         done += 1
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "scene-windows/s", "cores": 1, "kind": "port",
-            "sample": "%d scene-windows (V=%d, N=1 per forward like train.py:36-77) in %.1f s, oracle on torch CPU "
-                      "ops, 1 thread" % (done, obs_rel.shape[1], dt)}
+    return done, time.perf_counter() - t0
 
 
-def pmc_traffic(v, n):
-    """HBM bytes per stg_model_bwd launch from the committed rocprofv3 PMC passes (tools/gpu_traffic.sh:
-    FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    gfx950).  Counters cannot be collected inside this process, so the figure is the profiled one and only
-    reported for the workload it was profiled on (V=32, 2048 scene-windows); otherwise null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if (v, n) != (32, 2048) or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        t = json.load(f)
-    ks = ("txp_bwd_wave_kernel", "model_bwd_kernel", "txp_wgrad_kernel", "reduce_slabs_kernel")
-    if not all(k in t and "hbm_bytes_per_launch" in t[k] for k in ks):
-        return None
-    return sum(t[k]["hbm_bytes_per_launch"] for k in ks)
+def cpu_baselines(v, budget_s, counts=None):
+    done, dt = cpu_worker_loop(v, budget_s, 1, counts)
+    one = {"value": done / dt, "unit": "scene-windows/s", "cores": 1, "kind": "port",
+           "sample": "%d scene-windows (V=%s, N=1 per forward like train.py:36-77) in %.1f s, oracle on torch CPU ops, "
+                     "1 thread" % (done, v if counts is None else "ragged", dt)}
+    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--peds", str(v),
+                               "--cpu-seconds", str(budget_s)], stdout=subprocess.PIPE, text=True,
+                              env=dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1"))
+             for i in range(cores)]
+    tot, tmax = 0, 0.0
+    for p in procs:
+        o, _ = p.communicate()
+        try:
+            d, t = o.strip().split()[-2:]
+            tot += int(d)
+            tmax = max(tmax, float(t))
+        except Exception:
+            pass
+    many = {"value": tot / tmax if tmax > 0 else None, "unit": "scene-windows/s", "cores": cores, "kind": "port",
+            "sample": "%d scene-windows by %d single-threaded workers (one per core, data parallel over scenes like the "
+                      "GPU path) in %.1f s" % (tot, cores, tmax)}
+    return one, many
 
 
+# ------------------------------------------------------------------------------------------
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=2048, help="scene-windows per GPU")
-    ap.add_argument("--peds", type=int, default=32, help="pedestrians per scene-window (V)")
-    ap.add_argument("--ragged", choices=("shuffled", "sorted"), default=None,
-                    help="ragged batch: pedestrians per scene drawn from the eth/train histogram (padded to the "
-                         "largest draw); 'sorted' orders the scenes by crowd size")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
+    args = parse_args()
+    if args.cpu_worker >= 0:                  # child of cpu_baselines(): never touches the GPU
+        d, t = cpu_worker_loop(args.peds, args.cpu_seconds, 100 + args.cpu_worker)
+        print(d, t)
+        return 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)             # (before any torch.cuda call in this process)
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+
+    import numpy as np
+    import torch
     import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # RCCL ("nccl") over xGMI on a real node; STG_DIST_BACKEND=gloo lets several ranks share ONE GPU to
-        # rehearse the multi-rank code path on a single-GPU box
+        # RCCL ("nccl") over xGMI on a real node; STG_DIST_BACKEND=gloo lets several ranks share ONE GPU to rehearse
+        # the multi-rank code path on a single-GPU box
         backend = os.environ.get("STG_DIST_BACKEND", "nccl")
         local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
@@ -178,22 +275,39 @@ def main():
     from social_stgcnn_amd import ops
     from social_stgcnn_amd.model import social_stgcnn
     from social_stgcnn_amd.trainer import Trainer, broadcast_module
+    if args.dtype == "bf16":
+        if "bf16_store" not in ops.OPTIONS:
+            raise SystemExit("this build has no bf16-storage mode")
+        ops.OPTIONS["bf16_store"] = True
 
     n, v = args.batch, args.peds
-    counts, peds_d = None, None
-    if args.ragged:
-        counts = ragged_counts(n, seed=1 + rank, order=args.ragged)
-        v = int(counts.max())
-    obs_rel, target = synth_scenes(n, v, seed=1 + rank)
-    if counts is not None:
-        live = np.arange(v)[None, :] < counts[:, None]                  # (N,V)
-        obs_rel *= live[:, :, None, None]
-        target *= live[:, None, :, None]
-        peds_d = torch.from_numpy(counts).to(dev)
-    rel_d = torch.from_numpy(obs_rel).to(dev)
-    tgt_d = torch.from_numpy(target).to(dev)
-    nodes, adj = ops.adj_build(rel_d, peds_d)             # graph build stays on the device
-    x = nodes.permute(0, 3, 1, 2)                         # (N,2,T,V) strided view like train.py:48
+    n_sets = 2                                  # input batches that alternate from step to step
+    sets, n_windows = [], None
+    if args.dataset == "eth-train":
+        raw, n_windows = eth_train_batches(n, n_sets, seed=1 + rank)
+        for obs_rel, target, counts in raw:
+            sets.append((obs_rel, target, counts))
+    else:
+        for k in range(n_sets):
+            counts = None
+            vv = v
+            if args.ragged:
+                counts = ragged_counts(n, seed=1 + rank + 101 * k, order=args.ragged)
+                vv = int(counts.max())
+            obs_rel, target = synth_scenes(n, vv, seed=1 + rank + 101 * k)
+            if counts is not None:
+                live = np.arange(vv)[None, :] < counts[:, None]
+                obs_rel *= live[:, :, None, None]
+                target *= live[:, None, :, None]
+            sets.append((obs_rel, target, counts))
+    dsets = []
+    for obs_rel, target, counts in sets:
+        rel_d = torch.from_numpy(obs_rel).to(dev)
+        tgt_d = torch.from_numpy(target).to(dev)
+        peds_d = None if counts is None else torch.from_numpy(counts.astype(np.int32)).to(dev)
+        nodes, adj = ops.adj_build(rel_d, peds_d)             # graph build stays on the device
+        dsets.append(dict(rel=rel_d, tgt=tgt_d, peds=peds_d, nodes=nodes, adj=adj,
+                          x=nodes.permute(0, 3, 1, 2), v=obs_rel.shape[1]))   # (N,2,T,V) strided view like train.py:48
     weights = torch.full((n,), 1.0 / (n * world), device=dev)
 
     torch.manual_seed(0)
@@ -202,95 +316,179 @@ def main():
     broadcast_module(model)
     trainer = Trainer(model, lr=0.01)
 
+    def eager(d):
+        return lambda: trainer.step(d["x"], d["adj"], d["tgt"], d["peds"], weights)
     if args.no_graph:
-        def step():
-            return trainer.step(x, adj, tgt_d, peds_d, weights)
+        steps = [eager(d) for d in dsets]
     else:
-        step = trainer.capture(x, adj, tgt_d, peds_d, weights)      # the whole step as one hipGraph
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    ops.TIMER = ops.KernelTimer()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    # per-call device time of the forward / backward entry points: the same K steps once more, launched
-    # eagerly with HIP-event brackets on the launch stream (a replayed hipGraph cannot be bracketed per node)
-    for _ in range(args.steps):
-        trainer.step(x, adj, tgt_d, peds_d, weights)
-    torch.cuda.synchronize()
-    timer, ops.TIMER = ops.TIMER, None
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        steps = [trainer.capture(d["x"], d["adj"], d["tgt"], d["peds"], weights) for d in dsets]
 
+    def run_block(fns, k):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(k):
+            fns[i % len(fns)]()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    for i in range(args.warmup):
+        steps[i % len(steps)]()
+    first = run_block(steps, args.steps)
+    repeats = args.repeats if args.repeats > 0 else max(30, int(1.0 / max(first, 1e-6)) + 1)
+    if world > 1:                                   # every rank must run the same number of blocks
+        rr = torch.tensor([repeats], device=dev, dtype=torch.int64)
+        dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+        repeats = int(rr.item())
+    blocks = [first] + [run_block(steps, args.steps) for _ in range(repeats - 1)]
+    per_step = np.sort(np.asarray(blocks) / args.steps * 1e3)
+    ms_step = float(np.median(per_step))
+    p10, p90 = float(np.percentile(per_step, 10)), float(np.percentile(per_step, 90))
+
+    out = None
     if rank == 0:
-        ms_step = 1e3 * elapsed / args.steps
-        value = world * n * args.steps / elapsed
-        bwd_ms = timer.mean_ms("model_bwd")
-        fwd_ms = timer.mean_ms("model_fwd")
-        per_scene = [v] * n if counts is None else [int(c) for c in counts]
-        bwd_flops = sum(flops_per_window(c, fwd=False) for c in per_scene)
-        fwd_flops = sum(flops_per_window(c, bwd=False) for c in per_scene)
-        all_flops = sum(flops_per_window(c) for c in per_scene) / n
-        all_bytes = sum(bytes_per_window(c) for c in per_scene) / n
-        if counts is None:
-            workload = ("synthetic V=%d scene-windows, obs 8 / pred 12, batch %d per GPU, fp32 (BASELINE north-star: "
-                        "V<=32, batch=2048; SURVEY 8d generator)" % (v, n))
-        else:
+        value = world * n * 1e3 / ms_step
+        per_scene = []
+        for d, (_, _, counts) in zip(dsets, sets):
+            per_scene += [d["v"]] * n if counts is None else [int(c) for c in counts]
+        all_flops = sum(flops_per_window(c) for c in per_scene) / len(per_scene)
+        all_bytes = sum(bytes_per_window(c) for c in per_scene) / len(per_scene)
+        if args.dataset == "eth-train":
+            workload = ("REAL eth/train scene-windows (BASELINE configs[1]: %d of the %d windows per batch, seeded shuffle, "
+                        "2..57 pedestrians, mean %.1f, padded to %d), obs 8 / pred 12, batch %d per GPU, %s"
+                        % (n, n_windows, float(np.mean(per_scene)), max(d["v"] for d in dsets), n, args.dtype))
+        elif args.ragged:
             workload = ("synthetic ragged scene-windows, pedestrians per window drawn from the eth/train histogram "
-                        "(mean %.1f, max %d, %s order), obs 8 / pred 12, batch %d per GPU, fp32 (BASELINE configs[1] "
-                        "shape)" % (float(counts.mean()), v, args.ragged, n))
-        achieved = bwd_flops / (bwd_ms * 1e-3) / 1e12
+                        "(mean %.1f, max %d, %s order), obs 8 / pred 12, batch %d per GPU, %s"
+                        % (float(np.mean(per_scene)), max(d["v"] for d in dsets), args.ragged, n, args.dtype))
+        else:
+            workload = ("synthetic V=%d scene-windows, obs 8 / pred 12, batch %d per GPU, %s (BASELINE north-star: "
+                        "V<=32, batch=2048; SURVEY 8d generator)" % (v, n, args.dtype))
         out = {
             "metric": "scene-windows/sec fwd+bwd (obs=8,pred=12)",
             "value": value, "unit": "scene-windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.dtype == "f32" else "bf16-storage (fp32 accumulate, fp32 parameters)",
+            "data": "real (eth/train)" if args.dataset == "eth-train" else "synthetic",
             "launch": "eager" if args.no_graph else "hipGraph replay",
-            "config": {"workload": workload,
-                       "global_batch": n * world, "step": "forward + bivariate NLL + backward + "
-                       + ("RCCL all-reduce + " if world > 1 else "") + "SGD update",
+            "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "ms_per_step_median": ms_step,
+                       "ms_per_step_p10": p10, "ms_per_step_p90": p90, "ms_per_step_first_block": first / args.steps * 1e3,
+                       "timed_region_s": float(np.sum(blocks)), "input_batches_rotated": len(steps)},
+            "config": {"workload": workload, "global_batch": n * world,
+                       "step": "aggregation + forward + bivariate NLL + backward + "
+                               + ("ONE RCCL all-reduce + " if world > 1 else "") + "SGD update",
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": pmc_traffic(v, n) if counts is None else None,
-                         "traffic_note": "HBM bytes per stg_model_bwd launch, profiles/r01_pmc_traffic.json "
-                                         "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)",
-                         "kernel": "stg_model_bwd = txp_bwd_wave_kernel + model_bwd_kernel + txp_wgrad_kernel + "
-                                   "reduce_slabs_kernel (the backward of one batch)", "launch_ms": bwd_ms,
-                         "algorithmic_flop_per_launch": bwd_flops,
-                         "fwd_kernel": {"kernel": "stg_model_fwd = model_fwd_kernel + txp_fwd_wave_kernel", "launch_ms": fwd_ms,
-                                        "achieved": fwd_flops / (fwd_ms * 1e-3) / 1e12}},
-            "end_to_end": {"algorithmic_tflops": all_flops * value / 1e12,
-                           "algorithmic_gbs": all_bytes * value / 1e9},
+            "end_to_end": {"algorithmic_tflops": all_flops * value / 1e12, "algorithmic_gbs": all_bytes * value / 1e9},
         }
-        # stand-alone bandwidth kernels (north-star: achieved HBM GB/s vs the gfx950 peak)
-        adj_ms = time_kernel(lambda: ops.adj_build(rel_d, peds_d))
-        agg_in = torch.randn(n, 5, T_OBS, v, device=dev)
-        agg_ms = time_kernel(lambda: ops.spatial_agg(agg_in, adj))
-        adj_bytes = n * (64 * v + 32 * v * v + 64 * v)
-        agg_bytes = n * (32 * v * v + 2 * 160 * v)
-        out["kernels"] = {
-            "adj_build": {"ms": adj_ms, "GBps": adj_bytes / adj_ms / 1e6, "frac_hbm": adj_bytes / adj_ms / 1e6 / PEAK_HBM_GBS},
-            "spatial_agg_fwd": {"ms": agg_ms, "GBps": agg_bytes / agg_ms / 1e6,
-                                "frac_hbm": agg_bytes / agg_ms / 1e6 / PEAK_HBM_GBS},
-        }
+
+    # ---- per-kernel device time (HIP events the library records between its kernels) -> roofline ----------------
+    if not args.no_extras:
+        ops.TIMER = ops.KernelTimer()
+        for i in range(max(4, min(args.steps, 20))):
+            eager(dsets[i % len(dsets)])()
+        torch.cuda.synchronize()
+        timer, ops.TIMER = ops.TIMER, None
+        if rank == 0:
+            vmean = float(np.mean([c * 1.0 for c in per_scene]))
+            kern = []
+            for entry in ("model_fwd", "model_bwd"):
+                ms = timer.kernel_ms(entry)
+                for (name, flop, bound), t in zip(KERNELS[entry], ms):
+                    fl = sum(flop(c) for c in per_scene) / len(dsets)
+                    kern.append({"kernel": name, "entry": "stg_" + entry, "launch_ms": t, "bound": bound,
+                                 "algorithmic_flop_per_launch": fl,
+                                 "achieved_tflops": fl / (t * 1e-3) / 1e12 if t > 0 else None})
+            dom = max((k for k in kern if k["bound"] == "mfma"), key=lambda k: k["launch_ms"])
+            bwd_ms = sum(k["launch_ms"] for k in kern if k["entry"] == "stg_model_bwd")
+            bwd_fl = sum(flops_per_window(c, fwd=False) for c in per_scene) / len(dsets)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            if os.path.exists(tpath) and args.dataset == "synthetic" and not args.ragged and (v, n) == (32, 2048):
+                with open(tpath) as f:
+                    tj = json.load(f)
+                key = dom["kernel"].split(" ")[0]
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            out["roofline"] = {
+                "bound": "mfma", "achieved": dom["achieved_tflops"], "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": dom["achieved_tflops"] / PEAK_FP32_TFLOPS, "traffic": traffic,
+                "traffic_note": "HBM bytes per launch of this kernel, profiles/r02_pmc_traffic.json (rocprofv3 --pmc "
+                                "FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2; regenerate with tools/profile_all.sh)",
+                "kernel": dom["kernel"], "launch_ms": dom["launch_ms"],
+                "algorithmic_flop_per_launch": dom["algorithmic_flop_per_launch"],
+                "note": "dominant single MFMA kernel of the step; duration = mean over %d eager launches of HIP-event "
+                        "intervals recorded by the library on the launch stream; peak = fp32-input MFMA at 2.4 GHz"
+                        % len(timer.calls["model_bwd"]),
+                "kernels": kern,
+                "composite": {"kernel": "stg_model_bwd (all its kernels)", "launch_ms": bwd_ms,
+                              "algorithmic_flop_per_launch": bwd_fl,
+                              "achieved": bwd_fl / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else None,
+                              "frac": bwd_fl / (bwd_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS if bwd_ms > 0 else None},
+            }
+            _ = vmean
+
+        # ---- pipeline: adjacency build inside the step ---------------------------------------------------------
+        if not args.no_graph:
+            psteps = [trainer.capture(d["x"], d["adj"], d["tgt"], d["peds"], weights,
+                                      pre=(lambda d=d: ops.adj_build(d["rel"], d["peds"], out=(d["nodes"], d["adj"]))))
+                      for d in dsets]
+            for i in range(4):
+                psteps[i % len(psteps)]()
+            pb = np.sort([run_block(psteps, args.steps) for _ in range(max(5, repeats // 4))]) / args.steps * 1e3
+            if rank == 0:
+                out["pipeline"] = {"what": "the same step with utils.seq_to_graph (adj_build kernel) inside the captured "
+                                           "graph: relative trajectories in, updated weights out",
+                                   "ms_per_step": float(np.median(pb)), "value": world * n * 1e3 / float(np.median(pb)),
+                                   "unit": "scene-windows/s"}
+
+    # ---- stand-alone HBM kernels on a working set beyond the Infinity Cache (rank 0) --------------------------------
+    if rank == 0 and not args.no_extras:
+        vb = 32
+        nb = 16384                                            # adjacency: 16384 x 8 x 32 x 32 x 4 B = 537 MB > 256 MiB
+        rel_b, _ = synth_scenes(256, vb, 7)
+        rel_b = torch.from_numpy(np.tile(rel_b, (nb // 256, 1, 1, 1))).to(dev)
+        nodes_b, adj_b = ops.adj_build(rel_b)
+        adj_ms = time_kernel(torch, lambda: ops.adj_build(rel_b, out=(nodes_b, adj_b)))
+        agg_in = torch.randn(nb, 5, T_OBS, vb, device=dev)
+        agg_ms = time_kernel(torch, lambda: ops.spatial_agg(agg_in, adj_b))
+        agg_in.requires_grad_(True)
+        yb = ops.spatial_agg(agg_in, adj_b)
+        gy = torch.randn_like(yb)
+        aggb_ms = time_kernel(torch, lambda: torch.autograd.grad(yb, agg_in, gy, retain_graph=True))
+        del yb, gy
+        adj_bytes = nb * (64 * vb + 32 * vb * vb + 64 * vb)
+        agg_bytes = nb * (32 * vb * vb + 2 * 160 * vb)
+
+        def row(ms, nbytes):
+            return {"ms": ms, "GBps": nbytes / ms / 1e6, "frac_hbm": nbytes / ms / 1e6 / PEAK_HBM_GBS}
+        out["kernels"] = {"working_set": "N=%d scene-windows, V=%d: adjacency %.0f MB (> 256 MiB Infinity Cache)"
+                                         % (nb, vb, nb * 32 * vb * vb / 1e6),
+                          "adj_build": row(adj_ms, adj_bytes), "spatial_agg_fwd": row(agg_ms, agg_bytes),
+                          "spatial_agg_bwd": row(aggb_ms, agg_bytes)}
+        del rel_b, nodes_b, adj_b, agg_in
+        torch.cuda.empty_cache()
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(obs_rel, target, args.cpu_seconds, counts)
+            counts0 = sets[0][2]
+            one, many = cpu_baselines(dsets[0]["v"] if counts0 is None else int(np.mean(counts0) + 0.5), args.cpu_seconds)
+            out["cpu_baseline"] = one
+            out["cpu_baseline_all_cores"] = many
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -195,6 +195,24 @@ int stg_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, int32
 int stg_optim_step(float *params, float *grads, int64_t count, const float *lr_dev, float lr, float max_norm,
                    float *grad_norm, void *stream);
 
+/* Data-parallel training over scene-windows (the reference has no multi-GPU path): ONE all-reduce(sum) per
+ * optimizer step carries the flat gradient AND the exact sequential fold of the BatchNorm running statistics over the
+ * ranks ("R ranks x B scenes == one rank on the concatenated batch").
+ *   stg_dp_pack : pack = [ grads (n_params) | world slots of (n_buffers + 1) floats ]; the slot of `rank` receives
+ *                 acc = bn_after - (1-momentum)^{n_r} * bn_before and n_r = the rank's non-empty scenes (num_peds[i] > 0;
+ *                 num_peds NULL = N), every other slot 0.  bn_before / bn_after: the flat running statistics before /
+ *                 after this rank's stg_bn_fold.  pack holds n_params + world * (n_buffers + 1) floats.
+ *   (the caller all-reduces `pack` with SUM over the ranks: RCCL on MI355X)
+ *   stg_dp_fold : buffers = bn_before * keep^{sum_r n_r} + sum_r acc_r * keep^{sum_{j>r} n_j}, keep = 1 - momentum;
+ *                 the first n_params floats of `pack` are the summed gradient (feed them to stg_optim_step).         */
+int stg_dp_pack(const float *grads, const float *bn_before, const float *bn_after, const int32_t *num_peds, int N,
+                float momentum, int rank, int world, int n_params, int n_buffers, float *pack, void *stream);
+int stg_dp_fold(const float *pack, const float *bn_before, float momentum, int world, int n_params, int n_buffers,
+                float *buffers, void *stream);
+/* out[0] = sum_n weights[n] * values[n] (weights NULL: plain sum), fixed summation order: the reported group loss of
+ * train.train (train.py:58-67,76) from the per-scene losses of stg_nll_fwd.                                          */
+int stg_weighted_sum(const float *values, const float *weights, int N, float *out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * N2  evaluation tail of test.test (test.py:59-123) + metrics.ade/fde/nodes_rel_to_nodes_abs
  *     (metrics.py:21-75): per pedestrian the best-of-K average / final displacement error of K trajectories

@@ -69,6 +69,70 @@ __global__ __launch_bounds__(1024) void optim_step_kernel(float *__restrict__ p,
     }
 }
 
+// ---- data-parallel step: ONE collective carries the gradient and the BatchNorm fold ---------------
+// pack = [ gradient (n_p) | per rank r: acc_r (n_b), n_r ].  acc_r = after - keep^{n_r} before is what rank r's n_r
+// non-empty scenes added to its copy of the running statistics (after = keep^{n_r} before + acc_r); only the own slot
+// is non-zero, so the all-reduce(sum) of the pack is at the same time the gradient sum and an all-gather of the slots.
+__global__ __launch_bounds__(1024) void dp_pack_kernel(const float *__restrict__ grad, const float *__restrict__ before,
+                                                       const float *__restrict__ after,
+                                                       const int32_t *__restrict__ num_peds, int N, float momentum,
+                                                       int rank, int world, int n_p, int n_b, float *__restrict__ pack) {
+    __shared__ int cnt[16];
+    const int tid = threadIdx.x;
+    int c = 0;
+    for (int i = tid; i < N; i += blockDim.x) c += (!num_peds || num_peds[i] > 0) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((tid & 63) == 0) cnt[tid >> 6] = c;
+    __syncthreads();
+    int n_r = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) n_r += cnt[w];
+    const float own = (float)pow(1.0 - (double)momentum, (double)n_r);
+    for (int i = tid; i < n_p; i += blockDim.x) pack[i] = grad[i];
+    const int slot = n_b + 1;
+    for (int i = tid; i < world * slot; i += blockDim.x) {
+        const int r = i / slot, k = i - r * slot;
+        float v = 0.f;
+        if (r == rank) v = k < n_b ? after[k] - own * before[k] : (float)n_r;
+        pack[n_p + i] = v;
+    }
+}
+
+// after the all-reduce: running statistics of ONE process that saw rank 0's scenes, then rank 1's, ...:
+//   before * keep^{sum n} + sum_r acc_r * keep^{sum_{j>r} n_j}
+__global__ __launch_bounds__(256) void dp_fold_kernel(const float *__restrict__ pack, const float *__restrict__ before,
+                                                      float momentum, int world, int n_p, int n_b,
+                                                      float *__restrict__ buffers) {
+    const int slot = n_b + 1;
+    const double keep = 1.0 - (double)momentum;
+    for (int k = threadIdx.x; k < n_b; k += blockDim.x) {
+        double later = 0.0, acc = 0.0;               // later = scenes of the ranks behind r
+        for (int r = world - 1; r >= 0; --r) {
+            const float *s = pack + n_p + (int64_t)r * slot;
+            acc += (double)s[k] * pow(keep, later);
+            later += (double)s[n_b];
+        }
+        buffers[k] = (float)((double)before[k] * pow(keep, later) + acc);
+    }
+}
+
+// out[0] = sum_n w[n] * v[n] (w null: plain sum), one workgroup, fixed summation order
+__global__ __launch_bounds__(1024) void weighted_sum_kernel(const float *__restrict__ v, const float *__restrict__ w,
+                                                            int N, float *__restrict__ out) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    float acc = 0.f;
+    for (int i = tid; i < N; i += blockDim.x) acc = w ? fmaf(v[i], w[i], acc) : acc + v[i];
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[k];
+        out[0] = t;
+    }
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // One wave: C(16x16) = A(16xK) B(Kx16).  A operand: lane l holds A[l&15][4s + (l>>4)];
@@ -115,6 +179,35 @@ int stg_optim_step(float *params, float *grads, int64_t count, const float *lr_d
     hipLaunchKernelGGL(stg::optim_step_kernel, dim3(1), dim3(1024), 0, stg::as_stream(stream), params, grads, count,
                        lr_dev, lr, max_norm, grad_norm);
     STG_LAUNCH_CHECK("stg_optim_step");
+    return STG_OK;
+}
+
+int stg_dp_pack(const float *grads, const float *bn_before, const float *bn_after, const int32_t *num_peds, int N,
+                float momentum, int rank, int world, int n_params, int n_buffers, float *pack, void *stream) {
+    STG_REQUIRE(grads && bn_before && bn_after && pack, STG_EINVAL, "stg_dp_pack: null pointer");
+    STG_REQUIRE(N >= 0 && world >= 1 && rank >= 0 && rank < world && n_params >= 0 && n_buffers >= 0, STG_EINVAL,
+                "stg_dp_pack: bad sizes N=%d rank=%d world=%d", N, rank, world);
+    hipLaunchKernelGGL(stg::dp_pack_kernel, dim3(1), dim3(1024), 0, stg::as_stream(stream), grads, bn_before, bn_after,
+                       num_peds, N, momentum, rank, world, n_params, n_buffers, pack);
+    STG_LAUNCH_CHECK("stg_dp_pack");
+    return STG_OK;
+}
+
+int stg_dp_fold(const float *pack, const float *bn_before, float momentum, int world, int n_params, int n_buffers,
+                float *buffers, void *stream) {
+    STG_REQUIRE(pack && bn_before && buffers, STG_EINVAL, "stg_dp_fold: null pointer");
+    STG_REQUIRE(world >= 1 && n_params >= 0 && n_buffers >= 0, STG_EINVAL, "stg_dp_fold: bad sizes");
+    hipLaunchKernelGGL(stg::dp_fold_kernel, dim3(1), dim3(256), 0, stg::as_stream(stream), pack, bn_before, momentum,
+                       world, n_params, n_buffers, buffers);
+    STG_LAUNCH_CHECK("stg_dp_fold");
+    return STG_OK;
+}
+
+int stg_weighted_sum(const float *values, const float *weights, int N, float *out, void *stream) {
+    STG_REQUIRE(values && out && N >= 0, STG_EINVAL, "stg_weighted_sum: null pointer or negative N");
+    hipLaunchKernelGGL(stg::weighted_sum_kernel, dim3(1), dim3(1024), 0, stg::as_stream(stream), values, weights, N,
+                       out);
+    STG_LAUNCH_CHECK("stg_weighted_sum");
     return STG_OK;
 }
 

@@ -6,10 +6,11 @@
 // scene-window): a pure streaming kernel at full occupancy, so that the scene-resident kernels behind it start from
 // 96 V bytes per scene instead of paying A's HBM latency inside their dependent phases.
 //
-// One wave per scene-window (4 per workgroup).  x[n] (strided: the caller's permute(0,3,1,2) view) is staged in the
-// wave's LDS slice; lanes own (t, 4 consecutive w) strips when V is a multiple of 4 (16-byte loads along w, 8 rows in
-// flight per lane), single (t, w) columns otherwise (16 rows in flight).  Outputs are compact ([.][T][V_n]): the
-// layout of the saved arrays the block kernels index.
+// One 256-thread workgroup per scene-window.  x[n] (strided: the caller's permute(0,3,1,2) view) is staged in LDS;
+// threads own single (t, w) columns (16 row loads in flight each: at V = 32 all 256 threads of the workgroup stream,
+// 32 waves per CU keep HBM busy) or, for dense crowds (V a multiple of 4 with at least 256 strips), (t, 4 consecutive
+// w) strips with 16-byte loads, 8 rows in flight.  Outputs are compact ([.][T][V_n]): the layout of the saved arrays
+// the block kernels index.
 #include "model_common.hpp"
 
 namespace stg {
@@ -25,23 +26,22 @@ __global__ __launch_bounds__(256) void stgcn_agg_kernel(const float *__restrict_
                                                         float *__restrict__ out, int64_t out_stride, int64_t ax_off,
                                                         int64_t cs_off) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 4 + wave;
-    if (n >= N) return;
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x;
     int vi = num_peds ? num_peds[n] : V;
-    vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
+    vi = vi < 0 ? 0 : (vi > V ? V : vi);
     if (vi == 0) return;
-    float *xs = sm + wave * (CIN * T * V);            // [CIN][T][vi]
+    float *xs = sm;                                   // [CIN][T][vi]
     const float *xn = x + n * x_sn;
-    for (int e = lane; e < CIN * T * vi; e += 64) {
+    for (int e = tid; e < CIN * T * vi; e += 256) {
         const int v = e % vi, ct = e / vi, t = ct % T, c = ct / T;
         xs[e] = xn[c * x_sc + t * x_st + v * x_sv];
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     const float *an = adj + n * a_sn;
     float *axo = out + n * out_stride + ax_off, *cso = out + n * out_stride + cs_off;
     const int vq = (vi + VEC - 1) / VEC;
-    for (int q = lane; q < T * vq; q += 64) {
+    for (int q = tid; q < T * vq; q += 256) {
         const int t = q / vq, w0 = (q - t * vq) * VEC;
         float ax[CIN][VEC], cs[VEC];
 #pragma unroll
@@ -102,11 +102,13 @@ int launch_stgcn_agg(int cin, const float *x, int64_t x_sn, int64_t x_sc, int64_
                      int64_t a_sn, const int32_t *num_peds, int N, int V, float *out, int64_t out_stride, int64_t ax_off,
                      int64_t cs_off, hipStream_t st) {
     if (N == 0) return STG_OK;
-    const dim3 grid((N + 3) / 4), block(256);
-    const size_t lds = (size_t)4 * cin * T * V * sizeof(float);
+    const dim3 grid(N), block(256);
+    const size_t lds = (size_t)cin * T * V * sizeof(float);
     STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stgcn_agg: V=%d needs %zu bytes of LDS", V, lds);
     // 16-byte loads need 16-byte aligned rows: V a multiple of 4 and a 16-byte aligned base / batch stride
-    const bool vec = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(adj) & 15) == 0) && (a_sn % 4 == 0);
+    const int min_strips = diag_env("STG_AGG_VEC_STRIPS", 256);
+    const bool vec = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(adj) & 15) == 0) && (a_sn % 4 == 0) &&
+                     T * (V / 4) >= min_strips;
 #define STG_AGG(CI, VE)                                                                                          \
     do {                                                                                                         \
         if (lds > 64 * 1024) {                                                                                   \

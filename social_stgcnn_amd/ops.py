@@ -29,17 +29,24 @@ def _adj_layout(adj, n, t, v):
 # --------------------------------------------------------------------------------------------
 # R1/R2 adjacency build
 # --------------------------------------------------------------------------------------------
-def adj_build(seq_rel, num_peds=None, normalize=True):
+def adj_build(seq_rel, num_peds=None, normalize=True, out=None):
     """seq_rel (N,V,2,T) fp32 device tensor (any strides) -> nodes (N,T,V,2), adj (N,T,V,V).
-    Counterpart of utils.seq_to_graph (utils.py:29-53)."""
+    Counterpart of utils.seq_to_graph (utils.py:29-53).  `out` = (nodes, adj) to fill existing buffers (a captured
+    step keeps the graph build inside the hipGraph this way)."""
     require_gpu(seq_rel)
     _lib.as_f32(seq_rel, "seq_rel")
     n, v, c, t = seq_rel.shape
     if c != 2:
         raise ValueError("seq_rel must be (N,V,2,T)")
     peds = peds_arg(num_peds, n, seq_rel.device)
-    nodes = torch.empty((n, t, v, 2), device=seq_rel.device, dtype=torch.float32)
-    adj = torch.empty((n, t, v, v), device=seq_rel.device, dtype=torch.float32)
+    if out is not None:
+        nodes, adj = out
+        if tuple(nodes.shape) != (n, t, v, 2) or tuple(adj.shape) != (n, t, v, v) or not (
+                nodes.is_contiguous() and adj.is_contiguous()):
+            raise ValueError("adj_build: out = (nodes (N,T,V,2), adj (N,T,V,V)), contiguous")
+    else:
+        nodes = torch.empty((n, t, v, 2), device=seq_rel.device, dtype=torch.float32)
+        adj = torch.empty((n, t, v, v), device=seq_rel.device, dtype=torch.float32)
     sn, sv, sc, st = seq_rel.stride()
     check(lib().stg_adj_build(ptr(seq_rel), sn, sv, sc, st, ptr(peds), n, v, t, 1 if normalize else 0,
                               ptr(nodes), ptr(adj), stream_ptr()), "stg_adj_build")
@@ -406,6 +413,33 @@ def optim_step(flat_params, flat_grads, lr, max_norm=None, lr_dev=None, grad_nor
     check(lib().stg_optim_step(ptr(flat_params), ptr(flat_grads), flat_params.numel(), ptr(lr_dev), float(lr),
                                float(max_norm) if max_norm is not None else 0.0, ptr(grad_norm), stream_ptr()),
           "stg_optim_step")
+
+
+def dp_pack(flat_grad, bn_before, bn_after, num_peds, n_scenes, momentum, rank, world, pack):
+    """[gradient | this rank's BatchNorm contribution and scene count] into the ONE buffer a data-parallel step
+    all-reduces (stg_dp_pack).  pack: n_params + world * (n_buffers + 1) floats."""
+    require_gpu(flat_grad, bn_before, bn_after, pack)
+    peds = peds_arg(num_peds, n_scenes, flat_grad.device)
+    check(lib().stg_dp_pack(ptr(flat_grad), ptr(bn_before), ptr(bn_after), ptr(peds), int(n_scenes), float(momentum),
+                            int(rank), int(world), flat_grad.numel(), bn_before.numel(), ptr(pack), stream_ptr()),
+          "stg_dp_pack")
+
+
+def dp_fold(pack, bn_before, momentum, world, n_params, buffers):
+    """the exact sequential fold of the running statistics over the ranks from the all-reduced pack (stg_dp_fold)."""
+    require_gpu(pack, bn_before, buffers)
+    check(lib().stg_dp_fold(ptr(pack), ptr(bn_before), float(momentum), int(world), int(n_params), bn_before.numel(),
+                            ptr(buffers), stream_ptr()), "stg_dp_fold")
+
+
+def weighted_sum(values, weights=None):
+    """sum_n w_n v_n as a 1-element device tensor (one launch, fixed summation order)."""
+    require_gpu(values)
+    values = values.contiguous()
+    w = weights.to(torch.float32).contiguous() if weights is not None else None
+    out = torch.empty(1, device=values.device, dtype=torch.float32)
+    check(lib().stg_weighted_sum(ptr(values), ptr(w), values.numel(), ptr(out), stream_ptr()), "stg_weighted_sum")
+    return out[0]
 
 
 def best_of_k(y, target_rel, obs_last=None, num_peds=None, k=20, noise=None, seed=0):

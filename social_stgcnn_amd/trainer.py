@@ -69,6 +69,31 @@ def fold_bn_across_ranks(before, after, n_local, momentum, group=None, counts=No
     return before * total + contrib
 
 
+def pack_rank_slot(flat_grad, bn_before, bn_after, n_nonempty, momentum, rank, world):
+    """Pure-tensor statement of stg_dp_pack (the trainer launches the kernel; tests run this one under gloo on CPU):
+    [gradient | world slots of (acc_r, n_r)], only this rank's slot filled."""
+    n_p, n_b = flat_grad.numel(), bn_before.numel()
+    pack = torch.zeros(n_p + world * (n_b + 1), dtype=torch.float32, device=flat_grad.device)
+    pack[:n_p] = flat_grad
+    own = (1.0 - momentum) ** int(n_nonempty)
+    lo = n_p + rank * (n_b + 1)
+    pack[lo:lo + n_b] = bn_after - own * bn_before
+    pack[lo + n_b] = float(n_nonempty)
+    return pack
+
+
+def fold_from_pack(pack, bn_before, momentum, world, n_params):
+    """Pure-tensor statement of stg_dp_fold: the running statistics one process would hold after seeing rank 0's
+    scenes, then rank 1's, ... from the all-reduced pack."""
+    n_b = bn_before.numel()
+    keep = 1.0 - momentum
+    slots = pack[n_params:].reshape(world, n_b + 1).double()
+    counts = slots[:, n_b]
+    later = torch.flip(torch.cumsum(torch.flip(counts, [0]), 0), [0]) - counts        # scenes of the ranks behind r
+    acc = (slots[:, :n_b] * (keep ** later)[:, None]).sum(0)
+    return (bn_before.double() * keep ** counts.sum() + acc).float()
+
+
 def broadcast_module(model, src=0, group=None):
     """Initial parameter / buffer broadcast from rank `src`."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -158,38 +183,50 @@ class Trainer:
         # from dV_pred: no autograd graph through the loss, no separate scale / sum / expand kernels
         losses, dy = ops.bivariate_nll_with_grad(y.detach(), target, num_peds, weights)
         y.backward(dy)
-        total = losses.sum() if weights is None else torch.dot(losses, weights)
+        total = ops.weighted_sum(losses, weights)
         return total, losses, y.detach()
 
+    def _dp_buffers(self, flat_p, flat_b):
+        """the step's ONE collective buffer [gradient | world x (BatchNorm contribution, scene count)] + a snapshot
+        slot for the running statistics (allocated once: the captured step replays on them)."""
+        n = flat_p.numel() + self.world * (flat_b.numel() + 1)
+        if getattr(self, "_pack", None) is None or self._pack.numel() != n or self._pack.device != flat_p.device:
+            self._pack = torch.zeros(n, device=flat_p.device, dtype=torch.float32)
+            self._bn_before = torch.empty_like(flat_b)
+        return self._pack, self._bn_before
+
     def step(self, x, adj, target, num_peds=None, weights=None):
-        """forward_backward + gradient all-reduce + BatchNorm fold across ranks + SGD update."""
+        """forward_backward + [ONE all-reduce: gradient and BatchNorm fold across ranks] + SGD update.  No host
+        synchronisation anywhere: the scene counts the fold needs travel inside the collective."""
         model = self.model
-        if self.world > 1:
-            model.flat_parameters()                       # make sure the flat views exist
-            model._pb.ensure(self._bn_buffers())
-            before = model._pb.flat.clone()
-        total, losses, y = self.forward_backward(x, adj, target, num_peds, weights)
+        if self.world == 1:
+            total, losses, y = self.forward_backward(x, adj, target, num_peds, weights)
+            self._update(model.flat_parameters(), self._flat_grad())
+            return total, losses, y
         flat_p = model.flat_parameters()
-        flat_g = self._flat_grad()
-        if self.world > 1:
-            allreduce_flat(flat_g, self.group)
-            n_local = int(x.shape[0]) if num_peds is None else int((torch.as_tensor(num_peds) > 0).sum())
-            mom = model.st_gcns[0].tcn[0].momentum
-            flat_b = model._pb.flat
-            flat_b.copy_(fold_bn_across_ranks(before, flat_b.clone(), n_local, mom, self.group))
-        self._update(flat_p, flat_g)
+        flat_b = model._pb.ensure(self._bn_buffers())
+        pack, before = self._dp_buffers(flat_p, flat_b)
+        before.copy_(flat_b)
+        total, losses, y = self.forward_backward(x, adj, target, num_peds, weights)
+        mom = model.st_gcns[0].tcn[0].momentum
+        rank = dist.get_rank(self.group)
+        ops.dp_pack(self._flat_grad(), before, flat_b, num_peds, int(x.shape[0]), mom, rank, self.world, pack)
+        dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=self.group)          # the step's ONE collective
+        ops.dp_fold(pack, before, mom, self.world, flat_p.numel(), flat_b)
+        self._update(flat_p, pack[:flat_p.numel()])
         return total, losses, y
 
     # ---- hipGraph capture of the step (launch-bound at these sizes: ~15 kernels of 10-150 us) ----------
-    def capture(self, x, adj, target, num_peds=None, weights=None, warmup=3):
+    def capture(self, x, adj, target, num_peds=None, weights=None, warmup=3, pre=None):
         """Capture the training step on static input tensors and return `replay()`.
 
         Single rank: ONE hipGraph = forward + loss + backward + SGD update.
-        Several ranks: graph A = snapshot of the BatchNorm statistics + forward + loss + backward + packing of
-        [gradient | this rank's scaled BatchNorm contribution] into one flat buffer; then ONE eager all-reduce
-        (RCCL) of that 7,593-float buffer; graph B = BatchNorm fold + SGD update.  Every rank must hold the same
-        number of scenes (x.shape[0]).  x / adj / target / num_peds / weights must be device tensors that stay
-        alive; refresh their contents in place between replays."""
+        Several ranks: graph A = snapshot of the BatchNorm statistics + forward + loss + backward + stg_dp_pack
+        ([gradient | this rank's BatchNorm contribution and scene count] in one flat buffer); then ONE eager
+        all-reduce (RCCL) of that buffer (7,563 + world x 31 floats); graph B = stg_dp_fold + SGD update.
+        x / adj / target / num_peds / weights must be device tensors that stay alive; refresh their contents in place
+        between replays.  `pre` (optional callable) runs inside the graph ahead of the step -- e.g. the adjacency
+        build that fills x / adj from relative trajectories."""
         if num_peds is not None and not (torch.is_tensor(num_peds) and num_peds.is_cuda):
             raise ValueError("capture() needs num_peds as a device tensor (no host->device copies in a graph)")
         single = self.world == 1
@@ -204,6 +241,8 @@ class Trainer:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
+                if pre is not None:
+                    pre()
                 if single:
                     self.step(x, adj, target, num_peds, weights)
                 else:
@@ -217,6 +256,8 @@ class Trainer:
         if single:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
+                if pre is not None:
+                    pre()
                 out = self.step(x, adj, target, num_peds, weights)
             self._graph = graph
 
@@ -225,20 +266,19 @@ class Trainer:
                 return out
             return replay
 
-        n_p, n_b = flat_p.numel(), flat_b.numel()
+        n_p = flat_p.numel()
         rank = dist.get_rank(self.group)
-        own, later, total = bn_fold_scale([int(x.shape[0])] * self.world, rank, model.st_gcns[0].tcn[0].momentum)
-        pack = torch.zeros(n_p + n_b, device=flat_p.device, dtype=torch.float32)
-        before = torch.empty_like(flat_b)
+        mom = model.st_gcns[0].tcn[0].momentum
+        pack, before = self._dp_buffers(flat_p, flat_b)
         g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_a):
+            if pre is not None:
+                pre()
             before.copy_(flat_b)
             out = self.forward_backward(x, adj, target, num_peds, weights)
-            pack[:n_p].copy_(self._flat_grad())
-            torch.sub(flat_b, before, alpha=own, out=pack[n_p:])
-            pack[n_p:].mul_(later)
+            ops.dp_pack(self._flat_grad(), before, flat_b, num_peds, int(x.shape[0]), mom, rank, self.world, pack)
         with torch.cuda.graph(g_b, pool=g_a.pool()):
-            torch.add(pack[n_p:], before, alpha=total, out=flat_b)
+            ops.dp_fold(pack, before, mom, self.world, n_p, flat_b)
             self._update(flat_p, pack[:n_p])
         self._graph = (g_a, g_b)
 

@@ -17,6 +17,43 @@ def _data(dev, n, v, seed):
     return nodes.permute(0, 3, 1, 2).contiguous(), adj, torch.from_numpy(target).to(dev)
 
 
+def test_dp_pack_and_fold_kernels_equal_their_tensor_statement():
+    """stg_dp_pack / stg_dp_fold (three simulated ranks, ragged non-empty scene counts incl. empty scenes) against the
+    pure-tensor statement the gloo CPU test runs, and against the plain sequential momentum fold."""
+    from social_stgcnn_amd import ops
+    from social_stgcnn_amd.trainer import fold_from_pack, pack_rank_slot
+    dev = torch.device("cuda", 0)
+    world, n_p, n_b, m = 3, 7563, 30, 0.1
+    gen = torch.Generator().manual_seed(1)
+    before = torch.randn(n_b, generator=gen)
+    peds = [torch.tensor([3, 0, 5, 2, 0, 1, 9], dtype=torch.int32), torch.tensor([1, 1, 1], dtype=torch.int32),
+            torch.tensor([0, 0, 4, 4, 4, 4, 4, 4, 4, 4, 4], dtype=torch.int32)]
+    stats = [torch.randn(int((p > 0).sum()), n_b, generator=gen) for p in peds]
+    seq = before.clone()
+    packs_dev, packs_ref = [], []
+    for r in range(world):
+        after = before.clone()
+        for srow in stats[r]:
+            after = (1 - m) * after + m * srow
+            seq = (1 - m) * seq + m * srow
+        grad = torch.randn(n_p, generator=gen)
+        pk = torch.empty(n_p + world * (n_b + 1), device=dev)
+        ops.dp_pack(grad.to(dev), before.to(dev), after.to(dev), peds[r].to(dev), len(peds[r]), m, r, world, pk)
+        packs_dev.append(pk)
+        packs_ref.append(pack_rank_slot(grad, before, after, int((peds[r] > 0).sum()), m, r, world))
+        assert torch.allclose(pk.cpu(), packs_ref[-1], rtol=1e-6, atol=1e-7)
+    total_dev = torch.stack(packs_dev).sum(0)
+    out = torch.empty(n_b, device=dev)
+    ops.dp_fold(total_dev, before.to(dev), m, world, n_p, out)
+    ref = fold_from_pack(torch.stack(packs_ref).sum(0), before, m, world, n_p)
+    assert torch.allclose(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(out.cpu(), seq, rtol=1e-5, atol=1e-6)
+    # the reported loss reduction
+    v, w = torch.randn(777, generator=gen), torch.rand(777, generator=gen)
+    assert abs(float(ops.weighted_sum(v.to(dev), w.to(dev))) - float((v.double() * w.double()).sum())) < 1e-4
+    assert abs(float(ops.weighted_sum(v.to(dev))) - float(v.double().sum())) < 1e-4
+
+
 def _worker(rank, world, port, out_path, captured):
     import torch.distributed as dist
     from social_stgcnn_amd.model import social_stgcnn

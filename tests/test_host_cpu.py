@@ -39,7 +39,8 @@ def test_group_semantics():
 
 def _dp_worker(rank, world, port, out):
     import torch.distributed as dist
-    from social_stgcnn_amd.trainer import allreduce_flat, broadcast_module, fold_bn_across_ranks
+    from social_stgcnn_amd.trainer import (allreduce_flat, broadcast_module, fold_bn_across_ranks, fold_from_pack,
+                                           pack_rank_slot)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -63,6 +64,15 @@ def _dp_worker(rank, world, port, out):
         for i in range(5 + 3 * r):
             ref = (1 - m) * ref + m * stats[r, i]
     assert torch.allclose(folded, ref, rtol=1e-5, atol=1e-6), float((folded - ref).abs().max())
+    # the trainer's form: gradient, BatchNorm contribution and scene count in ONE all-reduced buffer (what stg_dp_pack /
+    # stg_dp_fold do on the device), no count exchange beforehand
+    grad = torch.arange(40, dtype=torch.float32) * (rank + 1)
+    pack = pack_rank_slot(grad, before, after, n_local, m, rank, world)
+    assert pack.numel() == 40 + world * 31
+    dist.all_reduce(pack)
+    assert torch.equal(pack[:40], torch.arange(40, dtype=torch.float32) * sum(r + 1 for r in range(world)))
+    folded2 = fold_from_pack(pack, before, m, world, 40)
+    assert torch.allclose(folded2, ref, rtol=1e-5, atol=1e-6), float((folded2 - ref).abs().max())
     # initial broadcast
     lin = torch.nn.Linear(4, 3)
     broadcast_module(lin)
