@@ -222,7 +222,11 @@ def cpu_baselines(v, budget_s, counts=None):
     one = {"value": done / dt, "unit": "scene-windows/s", "cores": 1, "kind": "port",
            "sample": "%d scene-windows (V=%s, N=1 per forward like train.py:36-77) in %.1f s, oracle on torch CPU ops, "
                      "1 thread" % (done, v if counts is None else "ragged", dt)}
-    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    avail = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    # torch's autograd engine opens the GPU device node even for CPU-only work, and the GPU box admits at most 6
+    # processes with the device open: this process + 4 workers stays inside that bound (the workers scale linearly:
+    # they share nothing)
+    cores = min(avail, 4)
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--peds", str(v),
                                "--cpu-seconds", str(budget_s)], stdout=subprocess.PIPE, text=True,
                               env=dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1"))
@@ -237,8 +241,10 @@ def cpu_baselines(v, budget_s, counts=None):
         except Exception:
             pass
     many = {"value": tot / tmax if tmax > 0 else None, "unit": "scene-windows/s", "cores": cores, "kind": "port",
-            "sample": "%d scene-windows by %d single-threaded workers (one per core, data parallel over scenes like the "
-                      "GPU path) in %.1f s" % (tot, cores, tmax)}
+            "host_cores_available": avail,
+            "sample": "%d scene-windows by %d single-threaded worker processes (data parallel over scenes like the GPU "
+                      "path; capped at 4 by the GPU box's limit of 6 processes holding the device, which torch's "
+                      "autograd engine opens even for CPU work; %d cores available) in %.1f s" % (tot, cores, avail, tmax)}
     return one, many
 
 

@@ -52,7 +52,7 @@ pmc)
   rm -rf gpurun_out/$tag.pmc ;;
 sweep)
   for args in "--peds 4" "--peds 8" "--peds 16" "--peds 32" "--peds 64" "--peds 128 --batch 4096" "--batch 512" "--batch 128" "--ragged shuffled"; do
-    timeout -k 10 600 python bench.py --no-cpu-baseline --repeats 5 $args 2>/dev/null | tail -1 | python3 -c "
+    timeout -k 10 600 python bench.py --no-cpu-baseline --no-extras --repeats 8 --steps 20 $args 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('$args:', '%.3f M/s  %.3f ms/step' % (d['value']/1e6, d['ms_per_step']))" ; done | tee gpurun_out/$tag.sweep.log ;;
 *) echo "usage: tools/gpu.sh test|bench|prof|pmc|sweep ..."; exit 2 ;;
