@@ -58,6 +58,8 @@ def parse_args(argv=None):
                     help="eth-train: real ragged windows of tests/golden/data/eth_train (BASELINE configs[1])")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="bf16: bf16 STORAGE of saved activations / hand-offs (fp32 accumulate, fp32 parameters)")
+    ap.add_argument("--wg-path", action="store_true", help="force the workgroup-per-scene kernels (STG_OPT_WG_PATH)")
+    ap.add_argument("--wg-waves", type=int, default=0, help="waves per scene of the workgroup-per-scene kernels (0 auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-extras", action="store_true", help="skip the pipeline / stand-alone kernel / roofline legs")
@@ -281,6 +283,8 @@ def main():
     from social_stgcnn_amd import ops
     from social_stgcnn_amd.model import social_stgcnn
     from social_stgcnn_amd.trainer import Trainer, broadcast_module
+    ops.OPTIONS["wg_path"] = bool(args.wg_path)
+    ops.OPTIONS["wg_waves"] = int(args.wg_waves)
     if args.dtype == "bf16":
         if "bf16_store" not in ops.OPTIONS:
             raise SystemExit("this build has no bf16-storage mode")

@@ -117,6 +117,8 @@ typedef struct {
 
 #define STG_OPT_WG_PATH 1     /* run the workgroup-per-scene kernels even where the wave-per-scene path fits */
 #define STG_OPT_SPLIT_BF16 2  /* TXP input-gradient GEMMs on bf16 MFMAs with hi/lo-split operands (fp32 in/out) */
+#define STG_OPT_WAVE_PATH 4   /* keep the wave-per-scene kernels for small batches too (default: batches of fewer than  */
+                              /* 768 scenes of <= 40 pedestrians run the workgroup kernels, several waves per scene)     */
 
 int64_t stg_model_param_count(const stg_model_desc *d);
 int64_t stg_model_buffer_count(const stg_model_desc *d);

@@ -335,7 +335,11 @@ static size_t bwd_lds_bytes(const ModelLayout &L, int V, int waves) {
 
 // measured (profiles/): the st_gcn backward is fastest with ONE wave per scene up to V ~ 40 (no cross-wave
 // barriers in its ~15 block reductions), more waves only when a scene's rows no longer fit one wave's registers
-static int bwd_waves(const ModelLayout &L, int V) { return L.wg_waves ? L.wg_waves : (V <= 40 ? 1 : (V <= 80 ? 4 : 8)); }
+static int bwd_waves(const ModelLayout &L, int N, int V) {
+    int w = 0;
+    use_wave_path(L, N, V, &w);          // (small batches: more waves per scene, see use_wave_path)
+    return w ? w : (V <= 40 ? 1 : (V <= 80 ? 4 : 8));
+}
 
 static int bwd_grid_w(const ModelLayout &L, int N, int V, int waves) {
     const size_t lds = bwd_lds_bytes(L, V, waves);
@@ -348,7 +352,7 @@ static int bwd_grid_w(const ModelLayout &L, int N, int V, int waves) {
     if (const int g = diag_env("STG_BWD_GRID", 0)) grid = g > 0 ? g : grid;
     return grid < N ? grid : N;
 }
-static int bwd_grid(const ModelLayout &L, int N, int V) { return bwd_grid_w(L, N, V, bwd_waves(L, V)); }
+static int bwd_grid(const ModelLayout &L, int N, int V) { return bwd_grid_w(L, N, V, bwd_waves(L, N, V)); }
 // ragged batches padded beyond kBwdTierV: the scenes up to kBwdTierV pedestrians (most of a real batch) run in a
 // second launch with ONE wave per scene and the LDS image of V = kBwdTierV; slab rows of both launches are stacked
 constexpr int kBwdTierV = 32;
@@ -370,7 +374,7 @@ static bool bwd_carve(const ModelLayout &L, int N, int V, BwdCarve *c, WgradGeom
     int gs = bwd_grid_small(L, N, V);
     if (gs < 0) gs = 0;
     int64_t n_rows = g1 + gs;
-    if (txp_wave_fits(L, V) && N > n_rows) n_rows = N;
+    if (use_wave_path(L, N, V, nullptr) && N > n_rows) n_rows = N;
     c->rows = 0;
     int64_t fl = (n_rows * (L.n_blk_params + L.n_txp) + 3) & ~(int64_t)3;
     c->slab2 = fl;
@@ -433,7 +437,8 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     // the wave-per-scene kernels compute no input gradient (the reference never needs one: x is data), and their
     // saved pre-activations are laid out for themselves: a caller that wants dx runs BOTH passes on the workgroup
     // kernels (STG_OPT_WG_PATH in the descriptor)
-    const bool wave_path = txp_wave_fits(L, V);
+    int auto_waves = 0;
+    const bool wave_path = use_wave_path(L, N, V, &auto_waves);
     STG_REQUIRE(!(wave_path && dx), STG_EUNSUPPORTED,
                 "stg_model_bwd: dx is only computed by the workgroup-per-scene kernels: set STG_OPT_WG_PATH in the "
                 "descriptor of the forward and the backward call");
@@ -464,7 +469,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         if (rcw != STG_OK) return rcw;
         slab_rows = N;
     } else {
-        const int waves = bwd_waves(L, V);
+        const int waves = bwd_waves(L, N, V);
         const size_t lds = bwd_lds_bytes(L, V, waves);
         STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_bwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
                     kLdsBytes);

@@ -258,7 +258,8 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     a.x_sn = x_sn; a.x_sc = x_sc; a.x_st = x_st; a.x_sv = x_sv;
     a.adj = adj; a.a_sn = a_sn; a.num_peds = num_peds; a.N = N; a.V = V;
     a.y = y; a.ws = ws; a.ws_stride = ws_floats_per_scene(L, V); a.stats = stats;
-    const bool wave_path = txp_wave_fits(L, V);
+    int auto_waves = 0;
+    const bool wave_path = use_wave_path(L, N, V, &auto_waves);
     hipStream_t st = as_stream(stream);
     EventList evl{events, events ? n_events : 0, 0, st};
     evl.mark();
@@ -306,7 +307,7 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         return rcw;
     }
     int waves = V <= 12 ? 1 : (V <= 40 ? 2 : (V <= 80 ? 4 : 8));
-    if (L.wg_waves) waves = L.wg_waves;
+    if (auto_waves) waves = auto_waves;
     const size_t lds = fwd_lds_bytes(V, waves);
     STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stg_model_fwd: V=%d needs %zu bytes of LDS (> %d)", V, lds,
                 kLdsBytes);

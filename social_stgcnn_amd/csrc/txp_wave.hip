@@ -956,6 +956,17 @@ bool txp_wave_fits(const ModelLayout &L, int V) {
     return fwd <= 48 * 1024;        // at least three waves per CU
 }
 
+constexpr int kSmallBatch = 768;      // below this many scenes a wave per scene leaves most of the chip's wave slots empty
+
+bool use_wave_path(const ModelLayout &L, int N, int V, int *wg_waves) {
+    if (wg_waves) *wg_waves = L.wg_waves;
+    if (!txp_wave_fits(L, V)) return false;
+    if (N >= kSmallBatch || L.wg_waves != 0 || V > 40 || (L.flags & STG_OPT_WAVE_PATH)) return true;
+    // small batch of small scenes: 2048 resident wave slots / N scenes, at most the 8 waves a scene's tiles can use
+    if (wg_waves) *wg_waves = N <= 192 ? 8 : 4;
+    return false;
+}
+
 static size_t fwd_per_wave_floats(int v) { return (size_t)P * txp_sci(v) + ptab_floats(v); }
 static size_t bwd_per_wave_floats(int v) { return (size_t)plane_slot(v) + (size_t)P * C * v + bwd_ptab_floats(v); }
 constexpr int kMixSmallV = 32;

@@ -64,6 +64,11 @@ struct TxpBwdArgs {
 
 // true when the wave-per-scene path serves this model / V (else the workgroup-per-scene kernels run)
 bool txp_wave_fits(const ModelLayout &L, int V);
+// Path of a batch of N scenes: the wave-per-scene kernels when they fit AND the batch fills the chip with one wave
+// per scene; a small batch (fewer scenes than resident wave slots: every scene's latency chain is the step) runs the
+// workgroup-per-scene kernels with `*wg_waves` waves per scene instead (measured: N = 512 x 4 waves 2.9 vs 2.5 M
+// scene-windows/s, N = 128 x 8 waves 0.95 vs 0.70).  Forward and backward make the same choice from (L, N, V).
+bool use_wave_path(const ModelLayout &L, int N, int V, int *wg_waves);
 int launch_txp_fwd_wave(const TxpFwdArgs &a, hipStream_t st);
 int launch_txp_bwd_wave(const TxpBwdArgs &a, hipStream_t st);
 

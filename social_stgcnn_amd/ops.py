@@ -179,12 +179,16 @@ class FlatPack:
 #   wg_path     run the workgroup-per-scene kernels even where the wave-per-scene path fits (tests cover both)
 #   split_bf16  TXP input-gradient GEMMs on bf16 MFMAs with hi/lo-split operands (opt-in, fp32 in / out)
 #   wg_waves    0 = auto, or 1 / 2 / 4 / 8 waves per scene in the workgroup-per-scene kernels
-OPTIONS = {"wg_path": False, "split_bf16": False, "wg_waves": 0}
+#   wave_path   keep the wave-per-scene kernels for small batches too (default: batches below 768 scenes of <= 40
+#               pedestrians run the workgroup kernels with 4 or 8 waves per scene -- one wave per scene would leave
+#               most of the chip's wave slots empty)
+OPTIONS = {"wg_path": False, "split_bf16": False, "wg_waves": 0, "wave_path": False}
 
 
 def make_desc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, use_mdn, training,
               eps=1e-5, momentum=0.1):
-    flags = (_lib.OPT_WG_PATH if OPTIONS["wg_path"] else 0) | (_lib.OPT_SPLIT_BF16 if OPTIONS["split_bf16"] else 0)
+    flags = ((_lib.OPT_WG_PATH if OPTIONS["wg_path"] else 0) | (_lib.OPT_SPLIT_BF16 if OPTIONS["split_bf16"] else 0)
+             | (_lib.OPT_WAVE_PATH if OPTIONS["wave_path"] else 0))
     return ModelDesc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, 1 if use_mdn else 0,
                      1 if training else 0, eps, momentum, flags, int(OPTIONS["wg_waves"]))
 
