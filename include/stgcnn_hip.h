@@ -117,6 +117,10 @@ typedef struct {
 
 #define STG_OPT_WG_PATH 1     /* run the workgroup-per-scene kernels even where the wave-per-scene path fits */
 #define STG_OPT_SPLIT_BF16 2  /* TXP input-gradient GEMMs on bf16 MFMAs with hi/lo-split operands (fp32 in/out) */
+#define STG_OPT_BF16_STORE 8  /* bf16 STORAGE of what the forward saves for the backward and of the hand-offs between the  */
+                              /* backward's kernels (TXP planes a_l, pre-activations z_l, dz_l): half the bytes; compute,    */
+                              /* accumulation, parameters, inputs and V_pred stay fp32 (the forward result is unchanged).    */
+                              /* Wave-per-scene path only (one st_gcn block, V <= 68).                                       */
 #define STG_OPT_WAVE_PATH 4   /* keep the wave-per-scene kernels for small batches too (default: batches of fewer than  */
                               /* 768 scenes of <= 40 pedestrians run the workgroup kernels, several waves per scene)     */
 

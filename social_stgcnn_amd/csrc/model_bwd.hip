@@ -439,6 +439,11 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     // kernels (STG_OPT_WG_PATH in the descriptor)
     int auto_waves = 0;
     const bool wave_path = use_wave_path(L, N, V, &auto_waves);
+    (void)auto_waves;
+    STG_REQUIRE(wave_path || !(L.flags & STG_OPT_BF16_STORE), STG_EUNSUPPORTED,
+                "stg_model_bwd: bf16 storage (STG_OPT_BF16_STORE) is built for the wave-per-scene kernels only");
+    STG_REQUIRE(!((L.flags & STG_OPT_BF16_STORE) && (L.flags & STG_OPT_SPLIT_BF16)), STG_EUNSUPPORTED,
+                "stg_model_bwd: STG_OPT_BF16_STORE and STG_OPT_SPLIT_BF16 cannot be combined");
     STG_REQUIRE(!(wave_path && dx), STG_EUNSUPPORTED,
                 "stg_model_bwd: dx is only computed by the workgroup-per-scene kernels: set STG_OPT_WG_PATH in the "
                 "descriptor of the forward and the backward call");

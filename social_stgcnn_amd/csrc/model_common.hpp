@@ -47,6 +47,35 @@ int make_layout(const stg_model_desc *d, ModelLayout *lay);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// bf16 storage (STG_OPT_BF16_STORE): round-to-nearest-even fp32 -> bf16, four values packed into 8 bytes
+__device__ __forceinline__ unsigned bf16_bits(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ uint2 pack_bf16x4(const f32x4 &v) {
+    return make_uint2(bf16_bits(v[0]) | (bf16_bits(v[1]) << 16), bf16_bits(v[2]) | (bf16_bits(v[3]) << 16));
+}
+__device__ __forceinline__ f32x4 unpack_bf16x4(const uint2 &u) {
+    return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                 __uint_as_float(u.y & 0xffff0000u)};
+}
+// Row strides (in positions) of the SAVED position-major arrays.  fp32: the natural ones (vi + 2 with the border
+// columns for a plane, vi for dz).  bf16 storage: rounded up to even, so that every row of 24-byte positions starts
+// 16-byte aligned -- the weight-gradient kernel stages rows and column chunks with 16-byte LDS-DMA.
+__host__ __device__ inline int save_sw(int vi, bool bf16) { return bf16 ? (vi + 3) & ~1 : vi + 2; }
+__host__ __device__ inline int save_vw(int vi, bool bf16) { return bf16 ? (vi + 1) & ~1 : vi; }
+
+// a 4-channel vector of a position-major [pos][12] array: 16 bytes in fp32, 8 bytes in bf16 storage
+__device__ __forceinline__ void store_vec4(float *base, int vec, const f32x4 &v, bool bf16) {
+    if (bf16) reinterpret_cast<uint2 *>(base)[vec] = pack_bf16x4(v);
+    else reinterpret_cast<f32x4 *>(base)[vec] = v;
+}
+__device__ __forceinline__ f32x4 load_vec4(const float *base, int vec, bool bf16) {
+    if (bf16) return unpack_bf16x4(reinterpret_cast<const uint2 *>(base)[vec]);
+    return reinterpret_cast<const f32x4 *>(base)[vec];
+}
+
 // LDS geometry of one padded TXP plane set: rows = C + 2, row stride SW = vi + 2, channel stride SC
 // chosen == 16 (mod 32) so the four K-lanes groups of a 16x16x4 B-operand read hit disjoint banks.
 __host__ __device__ inline int txp_sw(int vi) { return vi + 2; }

@@ -260,6 +260,9 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     a.y = y; a.ws = ws; a.ws_stride = ws_floats_per_scene(L, V); a.stats = stats;
     int auto_waves = 0;
     const bool wave_path = use_wave_path(L, N, V, &auto_waves);
+    STG_REQUIRE(wave_path || !(L.flags & STG_OPT_BF16_STORE), STG_EUNSUPPORTED,
+                "stg_model_fwd: bf16 storage (STG_OPT_BF16_STORE) is built for the wave-per-scene kernels only "
+                "(one st_gcn block, input_feat 2, V <= 68, no STG_OPT_WG_PATH)");
     hipStream_t st = as_stream(stream);
     EventList evl{events, events ? n_events : 0, 0, st};
     evl.mark();

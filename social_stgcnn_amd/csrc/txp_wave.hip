@@ -206,7 +206,7 @@ __device__ __forceinline__ void wave_dma(const float *__restrict__ src, float *l
 template <int CINL, int KIND, bool REV>
 __device__ __forceinline__ void fwd_layer(const float (&wreg)[CINL * 9 / 4], const float *__restrict__ bias, float alpha,
                                           const float *in, float *out, const ptab_t *ptab,
-                                          int vi, int V, float *zsave, float *psave, float *yout) {
+                                          int vi, int V, float *zsave, float *psave, float *yout, bool bf16 = false) {
     const int kq = (threadIdx.x & 63) >> 4;
     const int SW = txp_sw(vi), SC = txp_sci(vi), npos = C * vi;
     f32x4 binit;
@@ -236,8 +236,8 @@ __device__ __forceinline__ void fwd_layer(const float (&wreg)[CINL * 9 / 4], con
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(4 * kq + r) * SC + pp] = av[r];
             if (zsave) {   // position-major [pos][12]: one 16-byte store per lane
-                *reinterpret_cast<f32x4 *>(zsave + g.pos[u] * P + 4 * kq) = z;
-                *reinterpret_cast<f32x4 *>(psave + (g.hh[u] * SW + g.ww[u] + 1) * P + 4 * kq) = av;   // rows 1..C of the padded plane
+                store_vec4(zsave, g.pos[u] * 3 + kq, z, bf16);
+                store_vec4(psave, (g.hh[u] * save_sw(vi, bf16) + g.ww[u] + 1) * 3 + kq, av, bf16);   // rows 1..C of the padded plane
             }
         }
     });
@@ -298,6 +298,7 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, const float *
     if (vi == 0) return;
     const int SW = txp_sw(vi), SC = txp_sci(vi);
     const float *Pm = params;
+    const bool bf16 = (L.flags & STG_OPT_BF16_STORE) != 0;        // bf16 storage of the saved planes / pre-activations
     float *wsn = a.ws ? a.ws + n * a.ws_stride : nullptr;
     float *statn = a.stats ? a.stats + (int64_t)n * L.stat_floats : nullptr;
 
@@ -331,6 +332,7 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, const float *
         // training: a_0 is saved position-major for the weight-gradient GEMM -- the C interior ROWS with their two
         // border columns, [C*SW][P] (16-byte stores); the saved planes a_1 .. a_L get their zero border columns here
         float *d2 = wsn + ws_plane_off(L, V, 0);
+        const int SWs = save_sw(vi, bf16);                         // row stride of the saved planes
         for (int h = 0; h < C; ++h)
             for (int e = lane; e < SW * 3; e += 64) {              // (position, channel quad)
                 const int col = e / 3, q = e - col * 3;
@@ -339,12 +341,12 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, const float *
                     const float *src = buf + (4 * q) * SC + (h + 3) * SW + col;
                     v = make_float4(src[0], src[SC], src[2 * SC], src[3 * SC]);
                 }
-                *reinterpret_cast<float4 *>(d2 + ((h * SW + col) * P + 4 * q)) = v;
+                store_vec4(d2, (h * SWs + col) * 3 + q, f32x4{v.x, v.y, v.z, v.w}, bf16);
             }
         if (lane < 2 * C * 3) {
-            const int b = lane / 3, q = lane - b * 3, pos = (b >> 1) * SW + ((b & 1) ? SW - 1 : 0);
+            const int b = lane / 3, q = lane - b * 3, pos = (b >> 1) * SWs + ((b & 1) ? SW - 1 : 0);
             for (int l = 0; l < L.L; ++l)
-                *reinterpret_cast<float4 *>(wsn + ws_plane_off(L, V, l + 1) + pos * P + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+                store_vec4(wsn + ws_plane_off(L, V, l + 1), pos * 3 + q, f32x4{0.f, 0.f, 0.f, 0.f}, bf16);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -360,7 +362,7 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, const float *
     // (one `s_waitcnt lgkmcnt(0)` per read) instead of batching them
     {
         float *zs = zs_of(0), *ps = ps_of(0);
-        fwd_layer<T, 0, false>(w0, Pm + L.txp_b[0], Pm[L.prelus], hi, lo, ptab, vi, V, zs, ps, nullptr);
+        fwd_layer<T, 0, false>(w0, Pm + L.txp_b[0], Pm[L.prelus], hi, lo, ptab, vi, V, zs, ps, nullptr, bf16);
         load_w_fwd<P>(w_of(1), wa);
         __builtin_amdgcn_wave_barrier();
         zero_row_slot(buf, C + 1, SW, SC);           // lo's bottom border held hi's padded row C - 1
@@ -374,9 +376,9 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, const float *
         __builtin_amdgcn_wave_barrier();
         auto run = [&](const float (&wr)[27]) {      // (register arrays: selected statically, never by reference)
             if (odd)
-                fwd_layer<P, 1, true>(wr, Pm + L.txp_b[l], Pm[L.prelus + l], lo, hi, ptab, vi, V, zs, ps, nullptr);
+                fwd_layer<P, 1, true>(wr, Pm + L.txp_b[l], Pm[L.prelus + l], lo, hi, ptab, vi, V, zs, ps, nullptr, bf16);
             else
-                fwd_layer<P, 1, false>(wr, Pm + L.txp_b[l], Pm[L.prelus + l], hi, lo, ptab, vi, V, zs, ps, nullptr);
+                fwd_layer<P, 1, false>(wr, Pm + L.txp_b[l], Pm[L.prelus + l], hi, lo, ptab, vi, V, zs, ps, nullptr, bf16);
         };
         if (in_a) {
             run(wa);
@@ -481,6 +483,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, const float *
     }
     const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi;
     const float *Pm = a.params;
+    const bool bf16 = (L.flags & STG_OPT_BF16_STORE) != 0;        // bf16 storage of z_l (read) and dz_l (written)
     const float *wsn = a.ws + n * a.ws_stride;
     const float *dyn = a.dy + (int64_t)n * (C * P) * V;
     wave_zero(dzb, (P * SC) >> 2);
@@ -527,7 +530,8 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, const float *
                 const int p = vv / 3, q = vv - p * 3;
                 const unsigned hw = ptab[p];
                 const float *src = dzb + (4 * q) * SC + ((int)(hw >> 8) + 1) * SW + ((int)(hw & 0xffu) + 1);
-                reinterpret_cast<f32x4 *>(dzo_out)[vv] = f32x4{src[0], src[SC], src[2 * SC], src[3 * SC]};
+                store_vec4(dzo_out, ((int)(hw >> 8) * save_vw(vi, bf16) + (int)(hw & 0xffu)) * 3 + q,
+                           f32x4{src[0], src[SC], src[2 * SC], src[3 * SC]}, bf16);
             }
         } else {
             // dz_l = d(a_{l+1}) * prelu'(z_l); z is position-major [pos][12]; dz also leaves for the
@@ -539,13 +543,12 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, const float *
             // HBM latency is paid once per layer, not once per element batch
             constexpr int UV = 8;
             const int nvec = (P * npos) >> 2;                       // P*npos is a multiple of 4
-            const f32x4 *zl4 = reinterpret_cast<const f32x4 *>(zl);
             for (int v0 = lane; v0 < nvec; v0 += 64 * UV) {
                 f32x4 zv[UV];
 #pragma unroll
                 for (int u = 0; u < UV; ++u) {
                     const int vv = v0 + 64 * u;
-                    zv[u] = vv < nvec ? zl4[vv] : f32x4{1.f, 1.f, 1.f, 1.f};
+                    zv[u] = vv < nvec ? load_vec4(zl, vv, bf16) : f32x4{1.f, 1.f, 1.f, 1.f};
                 }
 #pragma unroll
                 for (int u = 0; u < UV; ++u) {
@@ -568,7 +571,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, const float *
                             dzb[ch * SC + (h + 1) * SW + (w + 1)] = dz;
                             dzv[r] = dz;
                         }
-                        reinterpret_cast<f32x4 *>(dzo)[vv] = dzv;
+                        store_vec4(dzo, (h * save_vw(vi, bf16) + w) * 3 + q, dzv, bf16);   // (= vv in fp32: rows of vi)
                     }
                 }
             }
@@ -961,7 +964,7 @@ constexpr int kSmallBatch = 768;      // below this many scenes a wave per scene
 bool use_wave_path(const ModelLayout &L, int N, int V, int *wg_waves) {
     if (wg_waves) *wg_waves = L.wg_waves;
     if (!txp_wave_fits(L, V)) return false;
-    if (N >= kSmallBatch || L.wg_waves != 0 || V > 40 || (L.flags & STG_OPT_WAVE_PATH)) return true;
+    if (N >= kSmallBatch || L.wg_waves != 0 || V > 40 || (L.flags & (STG_OPT_WAVE_PATH | STG_OPT_BF16_STORE))) return true;
     // small batch of small scenes: 2048 resident wave slots / N scenes, at most the 8 waves a scene's tiles can use
     if (wg_waves) *wg_waves = N <= 192 ? 8 : 4;
     return false;

@@ -64,7 +64,7 @@ struct Item {
     const float *pl, *dz;  // the scene's saved plane a_l and dz_l of this layer
 };
 
-template <int CINL, int NBUF>
+template <int CINL, int NBUF, bool BF>
 __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, const int32_t *__restrict__ order,
                                             const int32_t *__restrict__ order_peds, const int32_t *__restrict__ num_peds,
                                             int layer, float *sm, int wg, int nwg) {
@@ -74,7 +74,12 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, const int32_t *_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nq = lane & 15, kq = lane >> 4;
     const int co_a = nq < P ? nq : P - 1;          // rows 12..15 of the tile are never written back
-    const int image = wgrad_image_floats(V), pslot = plane_slot(wgrad_image_v(V));
+    constexpr int ES = BF ? 2 : 4;                 // bytes per stored element (STG_OPT_BF16_STORE: bf16 planes and dz)
+    const int image = wgrad_image_floats(V, BF), pslot = wgrad_plane_floats(V, BF);
+    auto ld = [&](const float *base, int idx) -> float {          // element idx of a staged array
+        if (BF) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(base)[idx] << 16);
+        return base[idx];
+    };
     const int nch = wgrad_chunks(V), items = a.N * nch;
     const int64_t plane_off = ws_plane_off(L, V, layer), dzs_floats = dz_slot(V);
     int tapr[NTILE], tapc[NTILE], cic[NTILE];      // column (tap, ci) of this lane in every tile
@@ -116,6 +121,7 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, const int32_t *_
         if (vfull == 0 || chunk >= nc) return it;
         int wc = vfull;
         if (nc > 1) wc = (vfull + nc - 1) / nc;
+        if (BF && nc > 1) wc = (wc + 1) & ~1;          // (chunks start on even columns: 16-byte aligned rows)
         it.pl = a.ws + w.n * a.ws_stride + plane_off;
         it.dz = a.dzg + ((int64_t)w.n * (L.L + 1) + layer) * dzs_floats;
         it.vi = vfull;
@@ -128,33 +134,34 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, const int32_t *_
     auto stage = [&](const Item &it, float *buf) -> int {
         if (!it.valid || STG_SKIP(a, 64)) return 0;
         const int vi = it.vi, vc = it.vc, w0 = it.w0;
-        const int SW = txp_sw(vi), SWc = txp_sw(vc);
+        const int SWf = save_sw(vi, BF), VWf = save_vw(vi, BF);       // row strides of the saved arrays (positions)
+        const int SWc = save_sw(vc, BF), VWc = save_vw(vc, BF);       // row strides of the staged image
         // top and bottom border rows of the plane image are zeros (the saved plane holds the C interior rows)
         if (tid < 2 * SWc * 3) {
             const int b = tid / 3, q = tid - b * 3;
             const int pos = b < SWc ? b : (C + 1) * SWc + (b - SWc);
-            *reinterpret_cast<float4 *>(buf + pos * P + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+            store_vec4(buf, pos * 3 + q, f32x4{0.f, 0.f, 0.f, 0.f}, BF);
         }
         const float *pl = it.pl, *dz = it.dz;
         int issued = 0;
         if (vc == vi) {            // whole scene: two linear copies
-            const int nv0 = (C * SW * P) >> 2, nv1 = (P * C * vc) >> 2;
+            const int nv0 = (C * SWf * P * ES + 15) >> 4, nv1 = (C * VWf * P * ES + 15) >> 4;
             const int np0 = (nv0 + 63) >> 6, np1 = (nv1 + 63) >> 6;
             for (int q = wave; q < np0 + np1; q += kWaves) {
-                if (q < np0) dma_piece(pl, buf + SWc * P, nv0, q);
+                if (q < np0) dma_piece(pl, buf + (SWc * P * ES) / 4, nv0, q);
                 else dma_piece(dz, buf + pslot, nv1, q - np0);
                 ++issued;
             }
         } else {                   // column chunk: per row, the plane with its two halo columns and the dz columns
-            const int nvp = (SWc * P) >> 2, nvd = (vc * P) >> 2;
+            const int nvp = (SWc * P * ES + 15) >> 4, nvd = (vc * P * ES + 15) >> 4;
             const int npp = (nvp + 63) >> 6, npd = (nvd + 63) >> 6;
             for (int q = wave; q < C * (npp + npd); q += kWaves) {
                 if (q < C * npp) {
                     const int h = q / npp, pc = q - h * npp;
-                    dma_piece(pl + (int64_t)(h * SW + w0) * P, buf + (h + 1) * SWc * P, nvp, pc);
+                    dma_piece(pl + ((int64_t)(h * SWf + w0) * P * ES) / 4, buf + ((h + 1) * SWc * P * ES) / 4, nvp, pc);
                 } else {
                     const int q2 = q - C * npp, h = q2 / npd, pc = q2 - h * npd;
-                    dma_piece(dz + (int64_t)(h * vi + w0) * P, buf + pslot + h * vc * P, nvd, pc);
+                    dma_piece(dz + ((int64_t)(h * VWf + w0) * P * ES) / 4, buf + pslot + (h * VWc * P * ES) / 4, nvd, pc);
                 }
                 ++issued;
             }
@@ -165,7 +172,7 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, const int32_t *_
     auto compute = [&](const Item &it, const float *buf) {
         if (!it.valid || STG_SKIP(a, 128)) return;
         const float *plane = buf, *dzs = buf + pslot;
-        const int vc = it.vc, SW = txp_sw(vc), npos = C * vc, nsteps = (npos + 3) >> 2;
+        const int vc = it.vc, SW = save_sw(vc, BF), VW = save_vw(vc, BF), npos = C * vc, nsteps = (npos + 3) >> 2;
         // p / vc == (p * inv) >> 16 for p < 409 with inv = ceil(65536 / vc): from the float reciprocal, fixed up exactly
         unsigned inv = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)vc));
         while (inv * (unsigned)vc < 65536u) ++inv;
@@ -178,11 +185,11 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, const int32_t *_
             const bool ok = p < npos;
             const int pc = ok ? p : 0;
             const int hh = (int)(((unsigned)pc * inv) >> 16), ww = pc - hh * vc;
-            const float av = ok ? dzs[pc * P + co_a] : 0.f;
+            const float av = ok ? ld(dzs, (hh * VW + ww) * P + co_a) : 0.f;
             const int offb = ((hh + 1) * SW + (ww + 1)) * P;
             float raw[NTILE];
 #pragma unroll
-            for (int tl = 0; tl < NTILE; ++tl) raw[tl] = plane[boff[tl] + offb];
+            for (int tl = 0; tl < NTILE; ++tl) raw[tl] = ld(plane, boff[tl] + offb);
 #pragma unroll
             for (int tl = 0; tl < NTILE; ++tl)
                 acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bone[tl] ? 1.f : raw[tl], acc[tl], 0, 0, 0);
@@ -257,7 +264,7 @@ __device__ __forceinline__ void wgrad_layer(const WgradArgs &a, const int32_t *_
     }
 }
 
-template <int NBUF>
+template <int NBUF, bool BF>
 __global__ __launch_bounds__(kWaves * 64, 4) void txp_wgrad_kernel(const WgradArgs a, const int32_t *__restrict__ order,
                                                                    const int32_t *__restrict__ order_peds,
                                                                    const int32_t *__restrict__ num_peds) {
@@ -270,9 +277,9 @@ __global__ __launch_bounds__(kWaves * 64, 4) void txp_wgrad_kernel(const WgradAr
     const int wg = (int)blockIdx.x - a.wg_begin[layer];
     const int nwg = a.wg_begin[layer + 1] - a.wg_begin[layer];
     if (layer == 0)
-        wgrad_layer<Cfg::T, NBUF>(a, order, order_peds, num_peds, layer, sm, wg, nwg);
+        wgrad_layer<Cfg::T, NBUF, BF>(a, order, order_peds, num_peds, layer, sm, wg, nwg);
     else
-        wgrad_layer<Cfg::P, NBUF>(a, order, order_peds, num_peds, layer, sm, wg, nwg);
+        wgrad_layer<Cfg::P, NBUF, BF>(a, order, order_peds, num_peds, layer, sm, wg, nwg);
 }
 
 }  // namespace
@@ -281,7 +288,8 @@ __global__ __launch_bounds__(kWaves * 64, 4) void txp_wgrad_kernel(const WgradAr
 // images; the chip's workgroup slots are split over the layers in proportion to their MFMA work (layer 0 has 5 column
 // tiles, the others 7)
 bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
-    const size_t image = (size_t)wgrad_image_floats(V) * sizeof(float);
+    const bool bf16 = (L.flags & STG_OPT_BF16_STORE) != 0;
+    const size_t image = (size_t)wgrad_image_floats(V, bf16) * sizeof(float);
     const size_t row = (size_t)((Cfg::P * Cfg::P * 9 + Cfg::P + 3) & ~3) * sizeof(float) * kWaves;   // final reduction
     int nbuf = diag_env("STG_WGRAD_NBUF", 4);
     if (nbuf != 3) nbuf = 4;
@@ -317,14 +325,19 @@ bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
 
 int launch_txp_wgrad(const WgradArgs &w, const WgradGeom &g, hipStream_t st) {
     const dim3 grid(g.grid), block(kWaves * 64);
-#define STG_LAUNCH_WG(NB)                                                                                    \
+#define STG_LAUNCH_WG(NB, BF)                                                                                \
     do {                                                                                                     \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_wgrad_kernel<NB>),           \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_wgrad_kernel<NB, BF>),       \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);         \
         if (e_ != hipSuccess) return hip_fail(e_, "txp_wgrad: hipFuncSetAttribute");                         \
-        hipLaunchKernelGGL(txp_wgrad_kernel<NB>, grid, block, g.lds, st, w, w.order, w.order_peds, w.num_peds); \
+        hipLaunchKernelGGL((txp_wgrad_kernel<NB, BF>), grid, block, g.lds, st, w, w.order, w.order_peds, w.num_peds); \
     } while (0)
-    if (g.nbuf == 3) STG_LAUNCH_WG(3); else STG_LAUNCH_WG(4);
+    const bool bf16 = (w.lay.flags & STG_OPT_BF16_STORE) != 0;
+    if (g.nbuf == 3) {
+        if (bf16) STG_LAUNCH_WG(3, true); else STG_LAUNCH_WG(3, false);
+    } else {
+        if (bf16) STG_LAUNCH_WG(4, true); else STG_LAUNCH_WG(4, false);
+    }
 #undef STG_LAUNCH_WG
     STG_LAUNCH_CHECK("txp_wgrad");
     return STG_OK;

@@ -10,10 +10,17 @@ namespace stg {
 constexpr int kWgradChunkV = 32;
 __host__ __device__ inline int wgrad_chunks(int V) { return (V + kWgradChunkV - 1) / kWgradChunkV; }
 __host__ __device__ inline int wgrad_image_v(int V) { return V < kWgradChunkV ? V : kWgradChunkV; }
-// floats of one staged work item: the zero-bordered position-major plane a_l + dz_l
-__host__ __device__ inline int wgrad_image_floats(int V0) {
+// LDS floats of one staged work item: the zero-bordered position-major plane a_l, then dz_l (bf16 storage: half the
+// bytes, rows padded to an even number of positions -- save_sw / save_vw)
+__host__ __device__ inline int wgrad_plane_floats(int V0, bool bf16) {
     const int V = wgrad_image_v(V0);
-    return plane_slot(V) + dz_slot(V);
+    if (!bf16) return plane_slot(V);
+    return (((Cfg::C + 2) * save_sw(V, true) * Cfg::P) / 2 + 3) & ~3;
+}
+__host__ __device__ inline int wgrad_image_floats(int V0, bool bf16 = false) {
+    const int V = wgrad_image_v(V0);
+    if (!bf16) return plane_slot(V) + dz_slot(V);
+    return wgrad_plane_floats(V0, true) + (((Cfg::C * save_vw(V, true) * Cfg::P) / 2 + 3 + 4) & ~3);
 }
 // slab geometry: layer 0 has c_in = T, layers 1..L (L = output conv) have c_in = P; one row = [P][c_in][9] + [P]
 __host__ __device__ inline int wgrad_row_len(int layer) {

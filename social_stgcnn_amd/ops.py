@@ -182,13 +182,16 @@ class FlatPack:
 #   wave_path   keep the wave-per-scene kernels for small batches too (default: batches below 768 scenes of <= 40
 #               pedestrians run the workgroup kernels with 4 or 8 waves per scene -- one wave per scene would leave
 #               most of the chip's wave slots empty)
-OPTIONS = {"wg_path": False, "split_bf16": False, "wg_waves": 0, "wave_path": False}
+#   bf16_store  bf16 storage of the saved TXP activations and of the dz hand-off (STG_OPT_BF16_STORE): fp32 forward
+#               result, ~1e-3 relative error in the TXP weight / slope gradients; wave-per-scene path only
+OPTIONS = {"wg_path": False, "split_bf16": False, "wg_waves": 0, "wave_path": False, "bf16_store": False}
 
 
 def make_desc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, use_mdn, training,
               eps=1e-5, momentum=0.1):
     flags = ((_lib.OPT_WG_PATH if OPTIONS["wg_path"] else 0) | (_lib.OPT_SPLIT_BF16 if OPTIONS["split_bf16"] else 0)
-             | (_lib.OPT_WAVE_PATH if OPTIONS["wave_path"] else 0))
+             | (_lib.OPT_WAVE_PATH if OPTIONS["wave_path"] else 0)
+             | (_lib.OPT_BF16_STORE if OPTIONS["bf16_store"] else 0))
     return ModelDesc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, 1 if use_mdn else 0,
                      1 if training else 0, eps, momentum, flags, int(OPTIONS["wg_waves"]))
 

@@ -784,6 +784,56 @@ def test_every_crowd_size_of_the_wave_path(dev):
     assert max(worst.values()) < 1e-4
 
 
+def test_bf16_storage_mode_measured_error(dev, monkeypatch):
+    """BASELINE configs[2]: STG_OPT_BF16_STORE keeps the saved TXP planes a_l, the pre-activations z_l and the dz_l
+    hand-off in bf16 (fp32 compute, accumulation, parameters, inputs).  What that costs, measured against the fp32
+    oracle on a ragged batch (2..57 pedestrians): V_pred and the loss are UNCHANGED (the forward computes from its
+    fp32 LDS images: the north-star's 1e-4 bar on the five Gaussian parameters holds); the st_gcn block gradients stay at
+    fp32 accuracy (the input-gradient chain only needs the sign of z); the TXP weight / bias and PReLU slope gradients
+    carry the bf16 rounding of a_l / dz_l / z_l: up to ~1e-3 of the tensor's largest entry."""
+    from social_stgcnn_amd import ops
+    from social_stgcnn_amd.metrics import bivariate_loss
+    O = _oracle()
+    monkeypatch.setitem(ops.OPTIONS, "bf16_store", True)
+    counts = [57, 2, 33, 17, 8, 32, 5, 40]
+    vmax = max(counts)
+    rels = [_synthetic_scene(vmax, 300 + i) for i in range(len(counts))]
+    for r, c in zip(rels, counts):
+        r[c:] = 0.0
+    m = _model(dev, seed=11).train()
+    state = {k: val.detach().cpu().clone() for k, val in m.state_dict().items()}
+    keys = [k for k, _ in m.named_parameters()]
+    params = {k: state[k].clone().requires_grad_(True) for k in keys}
+    work = dict(state)
+    work.update(params)
+    ref_losses, ref_pred = [], []
+    for rel, c in zip(rels, counts):
+        nodes, lap = O.seq_to_graph_np(rel[:c, :, :8])
+        tgt, _ = O.seq_to_graph_np(rel[:c, :, 8:])
+        l, vp = O.scene_loss(work, torch.from_numpy(nodes).unsqueeze(0).permute(0, 3, 1, 2), torch.from_numpy(lap),
+                             torch.from_numpy(tgt), True)
+        ref_losses.append(l)
+        ref_pred.append(vp.detach())
+    torch.stack(ref_losses).sum().backward()
+    rel_d = torch.from_numpy(np.stack(rels)).to(dev)
+    peds = torch.tensor(counts, dtype=torch.int32, device=dev)
+    nodes_d, adj_d = ops.adj_build(rel_d[..., :8], peds)
+    y, _ = m(nodes_d.permute(0, 3, 1, 2), adj_d, peds)
+    losses = bivariate_loss(y.permute(0, 2, 3, 1), rel_d[..., 8:].permute(0, 3, 1, 2).contiguous(), peds)
+    losses.sum().backward()
+    for i, c in enumerate(counts):
+        assert _maxdiff(y[i, :, :, :c].detach().permute(1, 2, 0).cpu().numpy(), ref_pred[i].numpy()) < 2e-5
+    assert _maxdiff(losses.detach().cpu().numpy(), torch.stack(ref_losses).detach().numpy()) < 2e-5
+    errs = _grad_errors(((name, p.grad) for name, p in m.named_parameters()),
+                        lambda name: None if params[name].grad is None else params[name].grad.numpy())
+    exact = {k: e for k, e in errs.items() if k.startswith("st_gcns")}
+    rounded = {k: e for k, e in errs.items() if k not in exact}
+    print("bf16 storage: V_pred / loss unchanged; worst relative gradient error: st_gcn block %.1e, TXP weights / "
+          "biases / PReLU slopes %.1e (%s)" % (max(exact.values()), max(rounded.values()), max(rounded, key=rounded.get)))
+    assert max(exact.values()) < 1e-5, exact               # measured 3e-7
+    assert max(rounded.values()) < 3e-3, rounded           # measured 7.8e-4 (prelus.1.weight): bf16 keeps 8 bits
+
+
 def test_split_bf16_input_gradient_variant(dev, monkeypatch):
     """ops.OPTIONS["split_bf16"] (opt-in, STG_OPT_SPLIT_BF16): the input-gradient GEMMs on bf16 MFMAs with hi/lo-split operands
     (hi*hi + hi*lo + lo*hi, fp32 accumulate).  Same checks, same tolerances as the fp32 path: the ragged batch against
