@@ -201,6 +201,17 @@ int stg_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, int32
 int stg_optim_step(float *params, float *grads, int64_t count, const float *lr_dev, float lr, float max_norm,
                    float *grad_norm, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * N1  TrajectoryDataset / DataLoader collation (utils.py:121-193, train.py:167-177) with the windowed dataset resident
+ *     in HBM: seq_rel_all = ragged concatenation of every window's relative trajectories (total_peds, 2, T_obs+T_pred);
+ *     win_start int32[n_windows+1] = pedestrian offsets of the windows; index int32[N] (DEVICE memory, NULL = windows
+ *     0..N-1) = the windows of this batch.  Writes obs_rel (N,V,2,T_obs) -- the input of stg_adj_build --, target
+ *     (N,T_pred,V,2) and num_peds (N), zero-padded to V slots (a window with more than V pedestrians is truncated:
+ *     pad to the dataset's largest crowd).  No host synchronisation: the whole training step can be captured with the
+ *     index refreshed in place.                                                                                     */
+int stg_gather_windows(const float *seq_rel_all, const int32_t *win_start, const int32_t *index, int n_windows, int N,
+                       int V, int T_obs, int T_pred, float *obs_rel, float *target, int32_t *num_peds, void *stream);
+
 /* Data-parallel training over scene-windows (the reference has no multi-GPU path): ONE all-reduce(sum) per
  * optimizer step carries the flat gradient AND the exact sequential fold of the BatchNorm running statistics over the
  * ranks ("R ranks x B scenes == one rank on the concatenated batch").

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "stg_optim_step": (c_i, [c_f, c_f, c_l, c_f, ctypes.c_float, ctypes.c_float, c_f, c_f]),
     "stg_bestofk_eval": (c_i, [c_f, c_l, c_l, c_l, c_l, c_f, c_f, c_f, c_f, ctypes.c_uint64, c_i, c_i, c_i, c_i,
                                c_f, c_f, c_f]),
+    "stg_gather_windows": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
     "stg_dp_pack": (c_i, [c_f, c_f, c_f, c_f, c_i, ctypes.c_float, c_i, c_i, c_i, c_i, c_f, c_f]),
     "stg_dp_fold": (c_i, [c_f, c_f, ctypes.c_float, c_i, c_i, c_i, c_f, c_f]),
     "stg_weighted_sum": (c_i, [c_f, c_f, c_i, c_f, c_f]),

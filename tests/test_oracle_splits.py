@@ -96,3 +96,20 @@ def test_oracle_reproduces_the_reference_eth_train_epoch():
             assert int(state[k]) == int(ref)
         else:
             np.testing.assert_allclose(state[k].detach().numpy(), ref, rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+# windows / pedestrians / largest crowd of all 15 split directories, measured with the reference's TrajectoryDataset
+# (SURVEY 8d): the known answers of the ingest.  The full dataset only exists next to the reference (build container).
+ALL_COUNTS = {"eth": ((2785, 29809, 57), (660, 5349, 42), (70, 181, 5)),
+              "hotel": ((2594, 29152, 57), (621, 5136, 42), (301, 1053, 8)),
+              "univ": ((2076, 9231, 14), (530, 2708, 13), (947, 24334, 57)),
+              "zara1": ((2322, 28010, 57), (605, 5118, 42), (602, 2253, 14)),
+              "zara2": ((2112, 25507, 57), (501, 4173, 42), (921, 5833, 14))}
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/datasets"), reason="full ETH/UCY tree only in the build container")
+@pytest.mark.parametrize("name", sorted(ALL_COUNTS))
+def test_ingest_counts_of_all_fifteen_split_directories(name):
+    for part, want in zip(("train", "val", "test"), ALL_COUNTS[name]):
+        w = data.load_windows(os.path.join("/root/reference/datasets", name, part), 8, 12, 1, with_non_linear=False)
+        assert (len(w), int(w.num_peds.sum()), int(w.num_peds.max())) == want, (name, part)
