@@ -380,15 +380,20 @@ __device__ __forceinline__ void txp_fwd_scene(const TxpFwdArgs &a, const float *
             else
                 fwd_layer<P, 1, false>(wr, Pm + L.txp_b[l], Pm[L.prelus + l], hi, lo, ptab, vi, V, zs, ps, nullptr, bf16);
         };
+        if (l == 1) STG_STAMP(12);
         if (in_a) {
             run(wa);
+            if (l == 1) STG_STAMP(9);
             load_w_fwd<P>(w_of(l + 1), wb);
         } else {
             run(wb);
+            if (l == 1) STG_STAMP(9);
             load_w_fwd<P>(w_of(l + 1), wa);
         }
+        if (l == 1) STG_STAMP(10);
         __builtin_amdgcn_wave_barrier();
         zero_row_slot(buf, odd ? 2 : C + 1, SW, SC);   // hi's top border held lo's padded row 2 / see layer 0
+        if (l == 1) STG_STAMP(11);
         in_a = !in_a;
         STG_STAMP(2 + l);
     }

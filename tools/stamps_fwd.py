@@ -31,7 +31,7 @@ names = ["dma+w0 wait", "layer0", "layer1", "layer2", "layer3", "(unused)", "(un
 for k in range(8):
     if k in (5, 6): continue
     col = d[:, k] if k < 5 else None
-names2 = ["st_gcn block", "a0 save+l0", "layer1", "layer2", "layer3", "out"]
+names2 = ["st_gcn block", "a0 save+l0", "layer1", "layer2", "layer3", "out"]   # (fine stamps 9..14 are shared: block phases / layer 1)
 seg = np.stack([st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2], st[:, 4] - st[:, 3], st[:, 5] - st[:, 4], st[:, 8] - st[:, 5]], 1)
 for k, nm in enumerate(names2):
     print("%-12s median %7d  p10 %7d  p90 %7d cycles" % (nm, np.median(seg[:, k]), np.percentile(seg[:, k], 10), np.percentile(seg[:, k], 90)))
