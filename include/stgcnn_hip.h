@@ -230,6 +230,16 @@ int stg_dp_fold(const float *pack, const float *bn_before, float momentum, int w
  * train.train (train.py:58-67,76) from the per-scene losses of stg_nll_fwd.                                          */
 int stg_weighted_sum(const float *values, const float *weights, int N, float *out, void *stream);
 
+/* The tail of a single-rank training step in ONE launch (the three jobs do not depend on each other; they run in
+ * different workgroups): the BatchNorm running-statistics fold of the forward just done (= stg_bn_fold; stats NULL
+ * skips it), total[0] = sum_n weights[n] * losses[n] (= stg_weighted_sum; losses or total NULL skips it) and
+ * clip_grad_norm_ + SGD on the flat parameters (= stg_optim_step).  Replaces train.py:58-76 + the per-forward
+ * running-statistics updates of model.py:114,123,140 for one group of scenes.                                        */
+int stg_train_tail(const stg_model_desc *d, const float *stats, const int32_t *num_peds, int N, float *buffers,
+                   int64_t *const *nbt, int n_bn, const float *losses, const float *weights, float *total,
+                   float *params, float *grads, int64_t count, const float *lr_dev, float lr, float max_norm,
+                   float *grad_norm, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * N2  evaluation tail of test.test (test.py:59-123) + metrics.ade/fde/nodes_rel_to_nodes_abs
  *     (metrics.py:21-75): per pedestrian the best-of-K average / final displacement error of K trajectories

@@ -64,6 +64,8 @@ _SIGNATURES = {
     "stg_dp_pack": (c_i, [c_f, c_f, c_f, c_f, c_i, ctypes.c_float, c_i, c_i, c_i, c_i, c_f, c_f]),
     "stg_dp_fold": (c_i, [c_f, c_f, ctypes.c_float, c_i, c_i, c_i, c_f, c_f]),
     "stg_weighted_sum": (c_i, [c_f, c_f, c_i, c_f, c_f]),
+    "stg_train_tail": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_i, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f, c_f,
+                             c_f, c_f, c_f, c_l, c_f, ctypes.c_float, ctypes.c_float, c_f, c_f]),
     "stg_selftest_mfma": (c_i, [c_f, c_f, c_i, c_f, c_f]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -1,5 +1,6 @@
 // Error reporting + small utility kernels (SGD step, MFMA self-test).
 #include "common.hpp"
+#include "tail_parts.hpp"
 #include <cstdlib>
 
 namespace stg {
@@ -34,39 +35,12 @@ __global__ void sgd_kernel(float *__restrict__ p, const float *__restrict__ g, i
     if (i < n) p[i] = p[i] - lr * g[i];
 }
 
-// clip_grad_norm_ (train.py:71-73) + SGD (train.py:197) over the flat buffers in ONE single-workgroup launch:
-// total = ||g||_2, coef = min(1, max_norm / (total + 1e-6)), g *= coef (in place, as torch does), p -= lr g.
-// lr comes from device memory when lr_dev != NULL, so a captured hipGraph follows the StepLR schedule.
+// clip_grad_norm_ + SGD over the flat buffers in ONE single-workgroup launch (body: tail_parts.hpp)
 __global__ __launch_bounds__(1024) void optim_step_kernel(float *__restrict__ p, float *__restrict__ g, int64_t n,
                                                           const float *__restrict__ lr_dev, float lr_host,
                                                           float max_norm, float *__restrict__ norm_out) {
     __shared__ float red[16];
-    const int tid = threadIdx.x;
-    const float lr = lr_dev ? lr_dev[0] : lr_host;
-    float coef = 1.f;
-    if (max_norm > 0.f || norm_out) {
-        float acc = 0.f;
-        for (int64_t i = tid; i < n; i += blockDim.x) acc = fmaf(g[i], g[i], acc);
-        acc = wave_sum(acc);
-        if ((tid & 63) == 0) red[tid >> 6] = acc;
-        __syncthreads();
-        float tot = 0.f;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
-        const float nrm = sqrtf(tot);
-        if (norm_out && tid == 0) norm_out[0] = nrm;
-        if (max_norm > 0.f) {
-            coef = max_norm / (nrm + 1e-6f);
-            coef = coef > 1.f ? 1.f : coef;
-        }
-    }
-    for (int64_t i = tid; i < n; i += blockDim.x) {
-        float gi = g[i];
-        if (max_norm > 0.f) {
-            gi *= coef;
-            g[i] = gi;
-        }
-        p[i] = p[i] - lr * gi;
-    }
+    optim_step_body(p, g, n, lr_dev, lr_host, max_norm, norm_out, red);
 }
 
 // ---- data-parallel step: ONE collective carries the gradient and the BatchNorm fold ---------------
@@ -116,24 +90,11 @@ __global__ __launch_bounds__(256) void dp_fold_kernel(const float *__restrict__ 
     }
 }
 
-// out[0] = sum_n w[n] * v[n] (w null: plain sum), one workgroup, fixed summation order
 __global__ __launch_bounds__(1024) void weighted_sum_kernel(const float *__restrict__ v, const float *__restrict__ w,
                                                             int N, float *__restrict__ out) {
     __shared__ float red[16];
-    const int tid = threadIdx.x;
-    float acc = 0.f;
-    for (int i = tid; i < N; i += blockDim.x) acc = w ? fmaf(v[i], w[i], acc) : acc + v[i];
-    acc = wave_sum(acc);
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
-    __syncthreads();
-    if (tid == 0) {
-        float t = 0.f;
-        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[k];
-        out[0] = t;
-    }
+    weighted_sum_body(v, w, N, out, red);
 }
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // One wave: C(16x16) = A(16xK) B(Kx16).  A operand: lane l holds A[l&15][4s + (l>>4)];
 // B operand: lane l holds B[4s + (l>>4)][l&15]; D: lane l, reg r -> C[(l>>4)*4 + r][l&15].

@@ -292,7 +292,10 @@ class _FusedModel(torch.autograd.Function):
                               ptr(adj_c), a_sn, ptr(peds), n, v, ptr(y), ptr(ws), ptr(stats), ptr(scr),
                               ev.arr if ev else None, ev.n if ev else 0, stream_ptr()),
               "stg_model_fwd")
-        if training:
+        if training and holder is not None and getattr(holder, "_defer_bn_fold", False):
+            # the trainer folds the running statistics in the step's tail launch (ops.train_tail)
+            holder._pending_bn = (desc, stats, peds, n, flat_buffers, nbt)
+        elif training:
             arr = (ctypes.c_void_p * len(nbt))(*[b.data_ptr() for b in nbt])
             # nbt[k] counts forwards of BatchNorm k; buffers are interleaved (mean, var) per BatchNorm, the
             # kernel bumps counter i for statistic row i < len(nbt): pass one pointer per BatchNorm.
@@ -420,6 +423,22 @@ def optim_step(flat_params, flat_grads, lr, max_norm=None, lr_dev=None, grad_nor
     check(lib().stg_optim_step(ptr(flat_params), ptr(flat_grads), flat_params.numel(), ptr(lr_dev), float(lr),
                                float(max_norm) if max_norm is not None else 0.0, ptr(grad_norm), stream_ptr()),
           "stg_optim_step")
+
+
+def train_tail(pending_bn, losses, weights, flat_params, flat_grads, lr, max_norm=None, lr_dev=None):
+    """The tail of a single-rank step in one launch (stg_train_tail): BatchNorm fold of `pending_bn` (what a fused
+    forward with a deferred fold left behind), the reported loss sum_n w_n loss_n, clip + SGD.  Returns the loss as a
+    0-d device tensor."""
+    require_gpu(losses, flat_params, flat_grads)
+    desc, stats, peds, n, flat_buffers, nbt = pending_bn
+    arr = (ctypes.c_void_p * len(nbt))(*[b.data_ptr() for b in nbt])
+    w = weights.to(torch.float32).contiguous() if weights is not None else None
+    out = torch.empty(1, device=losses.device, dtype=torch.float32)
+    check(lib().stg_train_tail(ctypes.byref(desc), ptr(stats), ptr(peds), n, ptr(flat_buffers), arr, len(nbt),
+                               ptr(losses), ptr(w), ptr(out), ptr(flat_params), ptr(flat_grads), flat_params.numel(),
+                               ptr(lr_dev), float(lr), float(max_norm) if max_norm is not None else 0.0, None,
+                               stream_ptr()), "stg_train_tail")
+    return out[0]
 
 
 def dp_pack(flat_grad, bn_before, bn_after, num_peds, n_scenes, momentum, rank, world, pack):

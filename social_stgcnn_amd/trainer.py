@@ -172,9 +172,10 @@ class Trainer:
         """clip_grad_norm_ + SGD update over the flat buffers: one launch (train.py:71-74)."""
         ops.optim_step(flat_p, flat_g, self.lr, self.clip_grad, self._lr_tensor(flat_p.device))
 
-    def forward_backward(self, x, adj, target, num_peds=None, weights=None):
+    def forward_backward(self, x, adj, target, num_peds=None, weights=None, defer_tail=False):
         """One fused forward + loss + backward.  x (N,2,T,V) (any strides), adj (N,T,V,V) or (T,V,V),
-        target (N,P,V,2).  Returns (weighted loss, per-scene losses, V_pred (N,5,P,V))."""
+        target (N,P,V,2).  Returns (weighted loss, per-scene losses, V_pred (N,5,P,V)).  defer_tail: leave the loss
+        total to the caller's tail launch (returned as None)."""
         model = self.model
         for p in model.parameters():
             p.grad = None
@@ -183,6 +184,8 @@ class Trainer:
         # from dV_pred: no autograd graph through the loss, no separate scale / sum / expand kernels
         losses, dy = ops.bivariate_nll_with_grad(y.detach(), target, num_peds, weights)
         y.backward(dy)
+        if defer_tail:
+            return None, losses, y.detach()
         total = ops.weighted_sum(losses, weights)
         return total, losses, y.detach()
 
@@ -200,8 +203,20 @@ class Trainer:
         synchronisation anywhere: the scene counts the fold needs travel inside the collective."""
         model = self.model
         if self.world == 1:
-            total, losses, y = self.forward_backward(x, adj, target, num_peds, weights)
-            self._update(model.flat_parameters(), self._flat_grad())
+            # forward + loss + backward, then ONE tail launch: running-statistics fold, reported loss, clip + SGD
+            model._defer_bn_fold, model._pending_bn = model.training, None
+            try:
+                _, losses, y = self.forward_backward(x, adj, target, num_peds, weights, defer_tail=model.training)
+            finally:
+                model._defer_bn_fold = False
+            flat_p = model.flat_parameters()
+            if model._pending_bn is None:                       # (eval-mode model: nothing to fold)
+                total = ops.weighted_sum(losses, weights)
+                self._update(flat_p, self._flat_grad())
+                return total, losses, y
+            total = ops.train_tail(model._pending_bn, losses, weights, flat_p, self._flat_grad(), self.lr,
+                                   self.clip_grad, self._lr_tensor(flat_p.device))
+            model._pending_bn = None
             return total, losses, y
         flat_p = model.flat_parameters()
         flat_b = model._pb.ensure(self._bn_buffers())

@@ -188,3 +188,42 @@ def test_trainer_clip_and_schedule_follow_the_reference_loop(dev):
             continue
         a, b = got[k].cpu().numpy(), prm.detach().numpy()
         assert np.abs(a - b).max() < 2e-5 * max(1.0, np.abs(b).max()), k
+
+
+def test_step_tail_launch_equals_its_three_separate_launches(dev):
+    """stg_train_tail (BatchNorm fold + reported loss + clip/SGD in ONE launch, what Trainer.step runs on one rank)
+    against the module-API sequence: forward with its own stg_bn_fold, stg_weighted_sum, stg_optim_step -- same
+    inputs, ragged scenes with an empty one; running statistics and parameters within 1 ulp of the summation order."""
+    import bench
+    from social_stgcnn_amd import ops
+    from social_stgcnn_amd.model import social_stgcnn
+    from social_stgcnn_amd.trainer import Trainer
+    n, v = 37, 9
+    obs_rel, target = bench.synth_scenes(n, v, 21)
+    nodes, adj = ops.adj_build(torch.from_numpy(obs_rel).to(dev))
+    x, tgt = nodes.permute(0, 3, 1, 2), torch.from_numpy(target).to(dev)
+    peds = torch.randint(1, v + 1, (n,), generator=torch.Generator().manual_seed(0)).to(torch.int32)
+    peds[5] = 0
+    peds = peds.to(dev)
+    w = torch.rand(n, generator=torch.Generator().manual_seed(1)).to(dev)
+    out = []
+    for fused in (True, False):
+        torch.manual_seed(9)
+        m = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3, pred_seq_len=12).to(dev).train()
+        tr = Trainer(m, lr=0.05, clip_grad=0.01)
+        if fused:
+            total, _, _ = tr.step(x, adj, tgt, peds, w)
+        else:
+            total, _, _ = tr.forward_backward(x, adj, tgt, peds, w)
+            tr._update(m.flat_parameters(), tr._flat_grad())
+        out.append((float(total), {k: t.detach().cpu().clone() for k, t in m.state_dict().items()}))
+    assert abs(out[0][0] - out[1][0]) <= 1e-6 * abs(out[1][0])
+    for k, ref in out[1][1].items():
+        got = out[0][1][k]
+        if "num_batches" in k:
+            assert torch.equal(got, ref), k
+        elif "running" in k:                 # same ordered fold, chunked over 1024 instead of 256 threads
+            assert torch.allclose(got, ref, rtol=1e-6, atol=1e-7), k
+        else:
+            assert float((got - ref).abs().max()) <= 2e-7 * max(1.0, float(ref.abs().max())), k
+    assert int(out[0][1]["st_gcns.0.tcn.0.num_batches_tracked"]) == n - 1
