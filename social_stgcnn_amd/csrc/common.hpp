@@ -43,8 +43,13 @@ static inline int diag_env(const char *, int dflt) { return dflt; }
 // (wave >= waves/2 shares a SIMD with wave - waves/2: waves are dealt to the SIMDs cyclically) starts `units` x 64 x 127
 // cycles late, about half a phase period, and from then on one partner stages while the other computes.
 __device__ __forceinline__ void stagger_start(int wave, int waves, int units) {
-    if (waves >= 2 && wave >= waves / 2)
+    // units < 0: no delay, the second half of the waves gets issue priority instead (-1 -> prio 1, ... -3 -> prio 3)
+    if (waves >= 2 && wave >= waves / 2) {
+        if (units == -1) __builtin_amdgcn_s_setprio(1);
+        else if (units == -2) __builtin_amdgcn_s_setprio(2);
+        else if (units <= -3) __builtin_amdgcn_s_setprio(3);
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 }
 
 // per-kernel device timing requested by the caller (stg_model_fwd / stg_model_bwd `events`)

@@ -302,6 +302,11 @@ bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
     g->waves = kWaves;
     g->nbuf = nbuf;
     g->lds = lds;
+    g->bf16mma = wgrad_bf16_fits(L, V) && !diag_env("STG_WGRAD_F32", 0);
+    if (g->bf16mma) {
+        wgrad_bf16_geom(g, V);
+        per_cu = 2;
+    }
     int total = kNumCU * per_cu;                       // resident workgroups on the chip
     if (const int v = diag_env("STG_WGRAD_GRID", 0)) total = v > 0 ? v : total;
     const int nl = L.L + 1;
@@ -324,6 +329,7 @@ bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
 }
 
 int launch_txp_wgrad(const WgradArgs &w, const WgradGeom &g, hipStream_t st) {
+    if (g.bf16mma) return launch_txp_wgrad_bf16(w, g, st);
     const dim3 grid(g.grid), block(kWaves * 64);
 #define STG_LAUNCH_WG(NB, BF)                                                                                \
     do {                                                                                                     \

@@ -32,6 +32,7 @@ __host__ __device__ inline int64_t wgrad_slab_base(int layer, int rows) {
 
 struct WgradGeom {
     int waves, nbuf, grid, rows;    // rows = slab rows per layer (= the largest workgroup count of a layer)
+    bool bf16mma;                   // txp_wgrad_bf16.hip (whole-scene fp32 items) instead of txp_wgrad.hip
     int wg_begin[kMaxTxp + 2];      // layer l owns workgroups [wg_begin[l], wg_begin[l+1])
     size_t lds;
 };
@@ -53,5 +54,9 @@ struct WgradArgs {
     int debug_skip;        // diagnostic builds only: 64 skip staging, 128 skip the MFMA loop
 };
 int launch_txp_wgrad(const WgradArgs &w, const WgradGeom &g, hipStream_t st);
+// txp_wgrad_bf16.hip: the same GEMM on the bf16 matrix pipe with exact three-piece operands
+bool wgrad_bf16_fits(const ModelLayout &L, int V);
+void wgrad_bf16_geom(WgradGeom *g, int V);
+int launch_txp_wgrad_bf16(const WgradArgs &w, const WgradGeom &g, hipStream_t st);
 
 }  // namespace stg

@@ -1,0 +1,307 @@
+// txp_wgrad_bf16 (K2, whole-scene fp32 items): the TXP-CNN weight / bias gradients
+//        dW_l[co][ci][tap] = sum_{scene,pos} dz_l[co][pos] a_l[ci][pos+tap],   db_l = sum dz_l
+// on v_mfma_f32_16x16x32_bf16 with fp32-exact operands: every fp32 value is split into three bf16 pieces (txp_conv_bf16.hpp:
+// x = x_h + x_m + x_l exactly) and the six products that reach 2^-24 are accumulated in fp32.  On gfx950 the fp32 MFMA
+// (v_mfma_f32_16x16x4_f32, what txp_wgrad.hip issues) holds the SIMD's VALU port for all of its 32 cycles; the bf16 MFMAs
+// take 16 cycles of the matrix pipe for 8x the K and run beside the VALU / LDS instructions of the other waves
+// (tools/micro/mfma_valu_overlap.hip).  Per 32 positions: 9 taps x 6 products x 16 = 864 pipe cycles instead of
+// 8 x 7 x 32 = 1792 VALU-blocking ones.
+//
+// GEMM shape: M = 12 out-channels (dz, 16-row tile), N = 16 input channels of ONE tap (12 real; nine tap tiles + a
+// ones tile for the bias), K = 32 positions per MFMA.  Both operands want 8 consecutive positions of one channel per
+// lane, the saved arrays are position-major ([pos][12], what the forward / input-gradient kernels write with 16-byte
+// stores): the LDS image keeps them position-major -- 72-byte records [3 pieces][12 channels] -- and the operands are
+// fetched with ds_read_b64_tr_b16, the transposing LDS read (4 positions x 16 channels -> lane = channel, 4 positions;
+// tools/micro/tr_read_probe.hip), so a tap shift is a whole number of records and every read is 8-byte aligned.
+//
+// A workgroup of 10 waves owns a layer and walks its share of the scenes: wave w takes K-step w >> 1 (32 positions;
+// a 32-pedestrian scene has 5) and half of the tap tiles (w & 1: taps 0..4 | taps 5..8 + bias), accumulates in VGPRs
+// for the whole launch, and the partial sums meet in LDS once at the end (fixed order, no atomics; same slab rows as
+// txp_wgrad.hip).  The fp32 arrays of a scene are fetched into registers TWO scenes ahead (plain global loads, 16
+// bytes per lane), split and written into one of two LDS images one scene ahead of its MFMAs: one s_barrier per scene.
+#include "txp_conv_bf16.hpp"
+#include "txp_wgrad.hpp"
+
+namespace stg {
+
+namespace {
+
+constexpr int C = Cfg::C, P = Cfg::P;
+constexpr int kWavesB = 10;
+constexpr int kRec = 72;                       // bytes of a position record: [h | m | l][12] bf16
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// bytes of one LDS image for batch width V: plane (C+2)(V+2) records, dz C*V records + one zero record
+__host__ __device__ inline int image_a_recs(int V) { return (C + 2) * (V + 2); }
+__host__ __device__ inline int image_bytes(int V) { return ((image_a_recs(V) + C * V + 1) * kRec + 15) & ~15; }
+
+struct Item {
+    int vi;
+    bool valid;
+    const float *pl, *dz;
+};
+
+__device__ __forceinline__ u32x2 tr_read(unsigned addr, int imm_sel) {
+    u32x2 r;
+    // (offset immediates: the three pieces of a record)
+    if (imm_sel == 0) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    else if (imm_sel == 1) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:24" : "=v"(r) : "v"(addr) : "memory");
+    else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:48" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+
+struct Op3 {            // one operand chunk (8 positions of the lane's channel), three pieces
+    u32x2 h[2], m[2], l[2];
+};
+__device__ __forceinline__ void read_op(unsigned a0, unsigned a1, Op3 &o) {
+    o.h[0] = tr_read(a0, 0);
+    o.h[1] = tr_read(a1, 0);
+    o.m[0] = tr_read(a0, 1);
+    o.m[1] = tr_read(a1, 1);
+    o.l[0] = tr_read(a0, 2);
+    o.l[1] = tr_read(a1, 2);
+}
+__device__ __forceinline__ void wait_op(Op3 &o) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(o.h[0]), "+v"(o.h[1]), "+v"(o.m[0]), "+v"(o.m[1]), "+v"(o.l[0]), "+v"(o.l[1])
+                 :
+                 : "memory");
+}
+__device__ __forceinline__ f32x4 mma(const u32x2 (&a)[2], const u32x2 (&b)[2], const f32x4 &c) {
+    const u32x4 av = {a[0].x, a[0].y, a[1].x, a[1].y}, bv = {b[0].x, b[0].y, b[1].x, b[1].y};
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cv::bf16x8, av), __builtin_bit_cast(cv::bf16x8, bv), c,
+                                                   0, 0, 0);
+}
+
+template <int CINL>
+__device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32_t *__restrict__ order,
+                                                 const int32_t *__restrict__ order_peds,
+                                                 const int32_t *__restrict__ num_peds, int layer, unsigned char *sm, int wg,
+                                                 int nwg) {
+    const ModelLayout &L = a.lay;
+    const int V = a.V, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = wave >> 1, hf = wave & 1;                    // K-step and tap half of this wave
+    const int kg = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;   // operand chunk, row and column quad of the tr reads
+    const int nq = lane & 15, kq = lane >> 4;                   // accumulator: column (input channel), row quad
+    const int img = image_bytes(V);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)sm;
+    const int items = a.N;
+    const int64_t plane_off = ws_plane_off(L, V, layer), dzs_floats = dz_slot(V);
+
+    f32x4 acc[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct Raw { int at, n, v; };
+    auto fetch = [&](int r) -> Raw {
+        Raw w{-1, 0, 0};
+        w.at = walk_item(r, wg, nwg, items, order != nullptr && a.serpentine);
+        if (w.at >= 0) {
+            w.n = order ? order[w.at] : w.at;
+            w.v = order ? order_peds[w.at] : (num_peds ? num_peds[w.at] : V);
+        }
+        return w;
+    };
+    auto finish = [&](const Raw &w) -> Item {
+        Item it{0, false, nullptr, nullptr};
+        if (w.at < 0) return it;
+        const int vfull = w.v < 0 ? 0 : (w.v > V ? V : w.v);
+        if (vfull == 0) return it;
+        it.pl = a.ws + w.n * a.ws_stride + plane_off;
+        it.dz = a.dzg + ((int64_t)w.n * (L.L + 1) + layer) * dzs_floats;
+        it.vi = vfull;
+        it.valid = true;
+        return it;
+    };
+    // ---- staging: task e of a scene = one 16-byte quad (4 channels of a position) of the plane rows or of dz ----------
+    // plane: C rows x (vi + 2) columns x 3 quads, saved [h][col][12] fp32; dz: C*vi positions x 3 quads.  At most
+    // 2 tasks per thread (kWgradChunkV = 32 pedestrians: 990 tasks, 640 threads).
+    struct Stage { f32x4 v[2]; };
+    auto load = [&](const Item &it, Stage &s) {
+        if (!it.valid || STG_SKIP(a, 64)) return;
+        const int na = C * (it.vi + 2) * 3, nz = C * it.vi * 3;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * kWavesB * 64;
+            if (e < na) s.v[u] = reinterpret_cast<const f32x4 *>(it.pl)[e];
+            else if (e < na + nz) s.v[u] = reinterpret_cast<const f32x4 *>(it.dz)[e - na];
+        }
+    };
+    auto convert = [&](const Item &it, const Stage &s, unsigned char *buf) {
+        if (!it.valid || STG_SKIP(a, 64)) return;
+        const int SWa = it.vi + 2, na = C * SWa * 3, nz = C * it.vi * 3;
+        unsigned char *dzimg = buf + image_a_recs(V) * kRec;
+        // zero border rows of the plane image (rows 0 and C + 1) and the zero record behind dz: 8-byte stores
+        for (int e = tid; e < 2 * SWa * 9 + 9; e += kWavesB * 64) {
+            unsigned char *dst;
+            if (e < SWa * 9) dst = buf + e * 8;
+            else if (e < 2 * SWa * 9) dst = buf + (C + 1) * SWa * kRec + (e - SWa * 9) * 8;
+            else dst = dzimg + C * it.vi * kRec + (e - 2 * SWa * 9) * 8;
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * kWavesB * 64;
+            if (e < na + nz) {
+                const bool isz = e >= na;
+                const int f = isz ? e - na : e, rec = f / 3, q = f - rec * 3;
+                // plane rows h = 0..C-1 land in image rows 1..C: record index + SWa
+                unsigned char *dst = (isz ? dzimg + rec * kRec : buf + (rec + SWa) * kRec) + 8 * q;
+                uint2 ph, pm, pl;
+                cv::split_pack4(s.v[u], ph, pm, pl);
+                *reinterpret_cast<uint2 *>(dst) = ph;
+                *reinterpret_cast<uint2 *>(dst + 24) = pm;
+                *reinterpret_cast<uint2 *>(dst + 48) = pl;
+            }
+        }
+    };
+    // ---- this wave's K-step of the scene staged in `buf` ------------------------------------------------------------
+    auto compute = [&](const Item &it, unsigned buf_off) {
+        if (!it.valid || STG_SKIP(a, 128)) return;
+        const int vi = it.vi, npos = C * vi, SWa = vi + 2;
+        if (32 * ks >= npos) return;
+        unsigned inv = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)vi));
+        while (inv * (unsigned)vi < 65536u) ++inv;
+        while ((inv - 1u) * (unsigned)vi >= 65536u) --inv;
+        const unsigned abase = lds0 + buf_off, zbase = abase + image_a_recs(V) * kRec;
+        unsigned za[2], aa[2];
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int p = 32 * ks + 8 * kg + 4 * rd + rq;
+            const bool ok = p < npos;
+            const int pc = ok ? p : 0;
+            const int hh = (int)(((unsigned)pc * inv) >> 16), ww = pc - hh * vi;
+            za[rd] = zbase + (ok ? p : npos) * kRec + 8 * cp;                         // past the end: the zero record
+            aa[rd] = abase + (ok ? ((hh + 1) * SWa + (ww + 1)) * kRec : SWa * kRec + kRec) + 8 * cp;
+        }
+        // one operand register set: the LDS latency of a tap's six reads is covered by the other four waves of the SIMD
+        // (five resident waves need <= 96 VGPRs; a second operand set spilled)
+        const int ntap = hf == 0 ? 5 : 4;                  // tap tiles of this half (the bias tile needs no plane operand)
+        Op3 dzo, ao;
+        read_op(za[0], za[1], dzo);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if (k < ntap) {
+                const int tap = hf * 5 + k;
+                const int shift = ((tap / 3 - 1) * SWa + (tap % 3 - 1)) * kRec;
+                read_op(aa[0] + shift, aa[1] + shift, ao);
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(ao.h[0]), "+v"(ao.h[1]), "+v"(ao.m[0]), "+v"(ao.m[1]), "+v"(ao.l[0]), "+v"(ao.l[1]),
+                               "+v"(dzo.h[0]), "+v"(dzo.h[1]), "+v"(dzo.m[0]), "+v"(dzo.m[1]), "+v"(dzo.l[0]), "+v"(dzo.l[1])
+                             :
+                             : "memory");
+                acc[k] = mma(dzo.h, ao.h, acc[k]);
+                acc[k] = mma(dzo.m, ao.h, acc[k]);
+                acc[k] = mma(dzo.h, ao.m, acc[k]);
+                acc[k] = mma(dzo.m, ao.m, acc[k]);
+                acc[k] = mma(dzo.l, ao.h, acc[k]);
+                acc[k] = mma(dzo.h, ao.l, acc[k]);
+            } else {
+                // bias: B = ones, every column of the tile becomes sum_pos dz[co][pos]
+                const u32x2 one[2] = {u32x2{0x3f803f80u, 0x3f803f80u}, u32x2{0x3f803f80u, 0x3f803f80u}};
+                acc[k] = mma(dzo.h, one, acc[k]);
+                acc[k] = mma(dzo.m, one, acc[k]);
+                acc[k] = mma(dzo.l, one, acc[k]);
+            }
+        }
+    };
+
+    // ---- the pipeline ---------------------------------------------------------------------------------------------
+    const int rounds = (items + nwg - 1) / nwg;        // (uniform over the workgroup: the barriers match)
+    Item q0 = finish(fetch(0)), q1 = finish(fetch(1)), q2 = finish(fetch(2));
+    Raw nxt = fetch(3);
+    Stage sa, sb;                                      // sa: the scene converted next, sb: the one after it
+    load(q0, sa);
+    load(q1, sb);
+    for (int r = 0; r < rounds; r += 2) {
+        // round r: scene q0 from `sa` into image 0; refill sa with scene r + 2
+        convert(q0, sa, sm);
+        load(q2, sa);
+        __builtin_amdgcn_s_barrier();
+        compute(q0, 0u);
+        q0 = q1; q1 = q2; q2 = finish(nxt); nxt = fetch(r + 4);
+        if (r + 1 >= rounds) break;
+        // round r + 1: scene (now q0) from `sb` into image 1; refill sb with scene r + 3
+        convert(q0, sb, sm + img);
+        load(q2, sb);
+        __builtin_amdgcn_s_barrier();
+        compute(q0, (unsigned)img);
+        q0 = q1; q1 = q2; q2 = finish(nxt); nxt = fetch(r + 5);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // each wave parks its tap tiles in its own LDS row ([P][CINL][9] weights + [P] biases: the parameters' own order);
+    // an entry is the sum over the five waves that own its tap half
+    constexpr int ROW = (P * CINL * 9 + P + 3) & ~3;
+    float *rowsm = reinterpret_cast<float *>(sm);
+    float *row = rowsm + wave * ROW;
+    if (kq < 3) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 4 * kq + r;
+                if (hf == 1 && k == 4) {
+                    if (nq == 0) row[P * CINL * 9 + co] = acc[k][r];
+                } else if (nq < CINL) {
+                    row[(co * CINL + nq) * 9 + hf * 5 + k] = acc[k][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int len = wgrad_row_len(layer);
+    float *dst = a.slab2 + wgrad_slab_base(layer, a.rows) + (int64_t)wg * len;
+    for (int e = tid; e < len; e += kWavesB * 64) {
+        const int tap = e < P * CINL * 9 ? e % 9 : 9;
+        const int h = tap >= 5 ? 1 : 0;
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) t += rowsm[(2 * s + h) * ROW + e];
+        dst[e] = t;
+    }
+}
+
+__global__ __launch_bounds__(kWavesB * 64, 5) void txp_wgrad_bf16_kernel(const WgradArgs a, const int32_t *__restrict__ order,
+                                                                         const int32_t *__restrict__ order_peds,
+                                                                         const int32_t *__restrict__ num_peds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+    int layer = 0;
+    while (layer < a.lay.L && (int)blockIdx.x >= a.wg_begin[layer + 1]) ++layer;
+    const int wg = (int)blockIdx.x - a.wg_begin[layer];
+    const int nwg = a.wg_begin[layer + 1] - a.wg_begin[layer];
+    if (layer == 0)
+        wgrad_bf16_layer<Cfg::T>(a, order, order_peds, num_peds, layer, smb, wg, nwg);
+    else
+        wgrad_bf16_layer<Cfg::P>(a, order, order_peds, num_peds, layer, smb, wg, nwg);
+}
+
+}  // namespace
+
+// whole-scene fp32 work items only (V <= kWgradChunkV, no bf16 storage): everything else runs txp_wgrad.hip
+bool wgrad_bf16_fits(const ModelLayout &L, int V) {
+    return V <= kWgradChunkV && !(L.flags & STG_OPT_BF16_STORE) && 2 * (size_t)image_bytes(V) * 2 <= (size_t)kLdsBytes;
+}
+
+void wgrad_bf16_geom(WgradGeom *g, int V) {
+    const size_t row = (size_t)((Cfg::P * Cfg::P * 9 + Cfg::P + 3) & ~3) * sizeof(float) * kWavesB;
+    size_t lds = 2 * (size_t)image_bytes(V);
+    if (lds < row) lds = row;
+    g->waves = kWavesB;
+    g->nbuf = 2;
+    g->lds = lds;
+}
+
+int launch_txp_wgrad_bf16(const WgradArgs &w, const WgradGeom &g, hipStream_t st) {
+    const dim3 grid(g.grid), block(kWavesB * 64);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_wgrad_bf16_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+    if (e != hipSuccess) return hip_fail(e, "txp_wgrad_bf16: hipFuncSetAttribute");
+    hipLaunchKernelGGL(txp_wgrad_bf16_kernel, grid, block, g.lds, st, w, w.order, w.order_peds, w.num_peds);
+    STG_LAUNCH_CHECK("txp_wgrad_bf16");
+    return STG_OK;
+}
+
+}  // namespace stg
