@@ -10,7 +10,7 @@
 // GEMM shape: M = 12 out-channels (dz, 16-row tile), N = 16 input channels of ONE tap (12 real; nine tap tiles + a
 // ones tile for the bias), K = 32 positions per MFMA.  Both operands want 8 consecutive positions of one channel per
 // lane, the saved arrays are position-major ([pos][12], what the forward / input-gradient kernels write with 16-byte
-// stores): the LDS image keeps them position-major -- 72-byte records [3 pieces][12 channels] -- and the operands are
+// stores): the LDS image keeps them position-major -- 96-byte records [3 pieces][12 channels + pad] -- and the operands are
 // fetched with ds_read_b64_tr_b16, the transposing LDS read (4 positions x 16 channels -> lane = channel, 4 positions;
 // tools/micro/tr_read_probe.hip), so a tap shift is a whole number of records and every read is 8-byte aligned.
 //
@@ -28,7 +28,8 @@ namespace {
 
 constexpr int C = Cfg::C, P = Cfg::P;
 constexpr int kWavesB = 10;
-constexpr int kRec = 72;                       // bytes of a position record: [h | m | l][12] bf16
+constexpr int kRec = 96;                       // bytes of a position record: [h | m | l][12 bf16 + 4 pad]
+constexpr int kPiece = 32;                     // bytes between the pieces of a record
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -46,8 +47,8 @@ __device__ __forceinline__ u32x2 tr_read(unsigned addr, int imm_sel) {
     u32x2 r;
     // (offset immediates: the three pieces of a record)
     if (imm_sel == 0) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-    else if (imm_sel == 1) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:24" : "=v"(r) : "v"(addr) : "memory");
-    else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:48" : "=v"(r) : "v"(addr) : "memory");
+    else if (imm_sel == 1) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:32" : "=v"(r) : "v"(addr) : "memory");
+    else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:64" : "=v"(r) : "v"(addr) : "memory");
     return r;
 }
 
@@ -118,27 +119,36 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     // ---- staging: task e of a scene = one 16-byte quad (4 channels of a position) of the plane rows or of dz ----------
     // plane: C rows x (vi + 2) columns x 3 quads, saved [h][col][12] fp32; dz: C*vi positions x 3 quads.  At most
     // 2 tasks per thread (kWgradChunkV = 32 pedestrians: 990 tasks, 640 threads).
+    // The loads are inline assembly on purpose: hipcc drains vmcnt(0) in front of every s_barrier for the loads IT
+    // tracks, which would retire the two scenes in flight at each scene's barrier; completion is counted by hand.
+    // EVERY call issues exactly two load instructions per wave (lanes without a task, and rounds past the last scene,
+    // re-read the first bytes of the workspace), so `landed` is one fixed s_waitcnt vmcnt(2); the destination is a
+    // read-write operand, which keeps a refilled set in the registers it already had (a renamed set would be copied
+    // at the loop edge -- while its data is still in flight).
     struct Stage { f32x4 v[2]; };
     auto load = [&](const Item &it, Stage &s) {
-        if (!it.valid || STG_SKIP(a, 64)) return;
-        const int na = C * (it.vi + 2) * 3, nz = C * it.vi * 3;
+        const bool live = it.valid && !STG_SKIP(a, 64);
+        const int na = live ? C * (it.vi + 2) * 3 : 0, nz = live ? C * it.vi * 3 : 0;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + u * kWavesB * 64;
-            if (e < na) s.v[u] = reinterpret_cast<const f32x4 *>(it.pl)[e];
-            else if (e < na + nz) s.v[u] = reinterpret_cast<const f32x4 *>(it.dz)[e - na];
+            const float *src = e < na ? it.pl + 4 * e : (e < na + nz ? it.dz + 4 * (e - na) : a.ws);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(s.v[u]) : "v"(src) : "memory");
         }
     };
+    // the set's loads have landed once only the two loads of the other set are outstanding
+    auto landed = [&](Stage &s) { asm volatile("s_waitcnt vmcnt(2)" : "+v"(s.v[0]), "+v"(s.v[1])::"memory"); };
     auto convert = [&](const Item &it, const Stage &s, unsigned char *buf) {
         if (!it.valid || STG_SKIP(a, 64)) return;
         const int SWa = it.vi + 2, na = C * SWa * 3, nz = C * it.vi * 3;
         unsigned char *dzimg = buf + image_a_recs(V) * kRec;
         // zero border rows of the plane image (rows 0 and C + 1) and the zero record behind dz: 8-byte stores
-        for (int e = tid; e < 2 * SWa * 9 + 9; e += kWavesB * 64) {
+        constexpr int U = kRec / 8;
+        for (int e = tid; e < 2 * SWa * U + U; e += kWavesB * 64) {
             unsigned char *dst;
-            if (e < SWa * 9) dst = buf + e * 8;
-            else if (e < 2 * SWa * 9) dst = buf + (C + 1) * SWa * kRec + (e - SWa * 9) * 8;
-            else dst = dzimg + C * it.vi * kRec + (e - 2 * SWa * 9) * 8;
+            if (e < SWa * U) dst = buf + e * 8;
+            else if (e < 2 * SWa * U) dst = buf + (C + 1) * SWa * kRec + (e - SWa * U) * 8;
+            else dst = dzimg + C * it.vi * kRec + (e - 2 * SWa * U) * 8;
             *reinterpret_cast<uint2 *>(dst) = make_uint2(0u, 0u);
         }
 #pragma unroll
@@ -152,8 +162,8 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
                 uint2 ph, pm, pl;
                 cv::split_pack4(s.v[u], ph, pm, pl);
                 *reinterpret_cast<uint2 *>(dst) = ph;
-                *reinterpret_cast<uint2 *>(dst + 24) = pm;
-                *reinterpret_cast<uint2 *>(dst + 48) = pl;
+                *reinterpret_cast<uint2 *>(dst + kPiece) = pm;
+                *reinterpret_cast<uint2 *>(dst + 2 * kPiece) = pl;
             }
         }
     };
@@ -169,7 +179,10 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
         unsigned za[2], aa[2];
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
-            const int p = 32 * ks + 8 * kg + 4 * rd + rq;
+            // K slots: lane group kg holds positions 4kg..4kg+3 and 16+4kg..16+4kg+3 of the step, so that the two groups of
+            // a 32-lane half read 8 CONSECUTIVE records: with 96-byte records (24 dwords = 3 x 8) their 32-byte rows
+            // tile the 64 banks exactly
+            const int p = 32 * ks + 16 * rd + 4 * kg + rq;
             const bool ok = p < npos;
             const int pc = ok ? p : 0;
             const int hh = (int)(((unsigned)pc * inv) >> 16), ww = pc - hh * vi;
@@ -213,10 +226,12 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     Item q0 = finish(fetch(0)), q1 = finish(fetch(1)), q2 = finish(fetch(2));
     Raw nxt = fetch(3);
     Stage sa, sb;                                      // sa: the scene converted next, sb: the one after it
+    sa.v[0] = sa.v[1] = sb.v[0] = sb.v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     load(q0, sa);
     load(q1, sb);
     for (int r = 0; r < rounds; r += 2) {
         // round r: scene q0 from `sa` into image 0; refill sa with scene r + 2
+        landed(sa);
         convert(q0, sa, sm);
         load(q2, sa);
         __builtin_amdgcn_s_barrier();
@@ -224,6 +239,7 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
         q0 = q1; q1 = q2; q2 = finish(nxt); nxt = fetch(r + 4);
         if (r + 1 >= rounds) break;
         // round r + 1: scene (now q0) from `sb` into image 1; refill sb with scene r + 3
+        landed(sb);
         convert(q0, sb, sm + img);
         load(q2, sb);
         __builtin_amdgcn_s_barrier();
@@ -264,7 +280,7 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     }
 }
 
-__global__ __launch_bounds__(kWavesB * 64, 5) void txp_wgrad_bf16_kernel(const WgradArgs a, const int32_t *__restrict__ order,
+__global__ __launch_bounds__(kWavesB * 64, 6) void txp_wgrad_bf16_kernel(const WgradArgs a, const int32_t *__restrict__ order,
                                                                          const int32_t *__restrict__ order_peds,
                                                                          const int32_t *__restrict__ num_peds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
