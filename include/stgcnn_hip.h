@@ -158,6 +158,17 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
                   const float *adj, int64_t a_sn, const int32_t *num_peds, int N, int V,
                   const float *dy, const float *ws, float *scratch, float *grad_params, float *dx,
                   void **events, int n_events, void *stream);
+
+/* stg_model_bwd fused with the loss (train.py:52-74: l = graph_loss(V_pred, V_tr); loss += l; loss.backward()): the
+ * backward starts from V_pred itself -- y, the (N, 5, pred, V) output of stg_model_fwd -- and the (N, pred, V, 2)
+ * target, computes d(sum_n weights[n] * loss_n)/dV_pred in its input stage (metrics.py:84-113, as stg_nll_fwd does)
+ * and writes losses[n] = bivariate_loss of scene n.  weights may be NULL (all ones).  Served by the wave-per-scene
+ * kernels only: STG_EUNSUPPORTED (nothing launched, no error message) on the workgroup path or with
+ * STG_OPT_SPLIT_BF16 -- call stg_nll_fwd + stg_model_bwd then.  No input gradient.                                 */
+int stg_model_bwd_nll(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
+                      int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj, int64_t a_sn, const int32_t *num_peds,
+                      int N, int V, const float *y, const float *target, const float *weights, float *losses,
+                      const float *ws, float *scratch, float *grad_params, void **events, int n_events, void *stream);
 /* Sequential-fold update of the BatchNorm running statistics with the per-scene statistics of a
  * batch, exactly as N successive reference forwards would (momentum update per scene,
  * model.py:114,123,140; SURVEY 7 'BatchNorm semantics').  Scenes with num_peds[n] == 0 are skipped.

@@ -18,6 +18,7 @@ DIAG = os.environ.get("STG_USE_DIAG_LIB", "0") not in ("", "0")
 LIB_PATH = os.path.join(CSRC, "libstgcnn_hip_diag.so" if DIAG else "libstgcnn_hip.so")
 ABI_VERSION = 5
 OPT_WG_PATH, OPT_SPLIT_BF16, OPT_WAVE_PATH, OPT_BF16_STORE = 1, 2, 4, 8
+EUNSUPPORTED = -2            # STG_EUNSUPPORTED
 
 c_f = ctypes.c_void_p          # device pointers travel as void*
 c_i = ctypes.c_int
@@ -52,6 +53,8 @@ _SIGNATURES = {
                             c_f, c_f, c_f, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f]),
     "stg_model_bwd": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_f, c_l, c_l, c_l, c_l, c_f, c_l, c_f, c_i, c_i,
                             c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f]),
+    "stg_model_bwd_nll": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_f, c_l, c_l, c_l, c_l, c_f, c_l, c_f, c_i, c_i,
+                                c_f, c_f, c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f]),
     "stg_bn_fold": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_i, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f]),
     "stg_nll_fwd": (c_i, [c_f, c_l, c_l, c_l, c_l, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f]),
     "stg_nll_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f]),

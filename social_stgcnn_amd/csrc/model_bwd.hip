@@ -405,10 +405,13 @@ int64_t stg_model_bwd_scratch_floats(const stg_model_desc *d, int N, int V) {
     return c.total;
 }
 
-int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
-                  int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj, int64_t a_sn, const int32_t *num_peds,
-                  int N, int V, const float *dy, const float *ws, float *scratch, float *grad_params, float *dx,
-                  void **events, int n_events, void *stream) {
+// dy = dV_pred, or (nll_target != null) V_pred itself: the wave-per-scene backward then computes the loss gradient in
+// its input stage and writes the per-scene losses (stg_model_bwd_nll)
+static int model_bwd_impl(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
+                          int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj, int64_t a_sn,
+                          const int32_t *num_peds, int N, int V, const float *dy, const float *nll_target,
+                          const float *nll_weights, float *nll_losses, const float *ws, float *scratch,
+                          float *grad_params, float *dx, void **events, int n_events, void *stream) {
     using namespace stg;
     BwdArgs a{};
     const int rc = make_layout(d, &a.lay);
@@ -444,6 +447,8 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
                 "stg_model_bwd: bf16 storage (STG_OPT_BF16_STORE) is built for the wave-per-scene kernels only");
     STG_REQUIRE(!((L.flags & STG_OPT_BF16_STORE) && (L.flags & STG_OPT_SPLIT_BF16)), STG_EUNSUPPORTED,
                 "stg_model_bwd: STG_OPT_BF16_STORE and STG_OPT_SPLIT_BF16 cannot be combined");
+    if (nll_target && (!wave_path || (L.flags & STG_OPT_SPLIT_BF16) || L.n_txp == 0))
+        return STG_EUNSUPPORTED;        // (no message: the caller falls back to stg_nll_fwd + stg_model_bwd)
     STG_REQUIRE(!(wave_path && dx), STG_EUNSUPPORTED,
                 "stg_model_bwd: dx is only computed by the workgroup-per-scene kernels: set STG_OPT_WG_PATH in the "
                 "descriptor of the forward and the backward call");
@@ -463,6 +468,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
         // K1 (wave per scene): TXP input-gradient chain + st_gcn block backward; one small-gradient row per scene
         TxpBwdArgs t{};
         t.lay = L; t.params = params; t.num_peds = num_peds; t.N = N; t.V = V; t.dy = dy; t.ws = ws;
+        t.nll_target = nll_target; t.nll_weights = nll_weights; t.nll_losses = nll_losses;
         t.x = x; t.x_sn = x_sn; t.x_sc = x_sc; t.x_st = x_st; t.x_sv = x_sv; t.adj = adj; t.a_sn = a_sn;
         t.ws_stride = a.ws_stride; t.dzg = dzg; t.rows = rows;
         t.tier = a.tier;
@@ -553,6 +559,23 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
     evl.mark();
     evl.finish();
     return STG_OK;
+}
+
+int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
+                  int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj, int64_t a_sn, const int32_t *num_peds,
+                  int N, int V, const float *dy, const float *ws, float *scratch, float *grad_params, float *dx,
+                  void **events, int n_events, void *stream) {
+    return model_bwd_impl(d, params, buffers, x, x_sn, x_sc, x_st, x_sv, adj, a_sn, num_peds, N, V, dy, nullptr, nullptr,
+                          nullptr, ws, scratch, grad_params, dx, events, n_events, stream);
+}
+
+int stg_model_bwd_nll(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
+                      int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj, int64_t a_sn, const int32_t *num_peds,
+                      int N, int V, const float *y, const float *target, const float *weights, float *losses,
+                      const float *ws, float *scratch, float *grad_params, void **events, int n_events, void *stream) {
+    if (!target || !losses || (N > 0 && !y)) return stg::fail(STG_EINVAL, "stg_model_bwd_nll: null pointer");
+    return model_bwd_impl(d, params, buffers, x, x_sn, x_sc, x_st, x_sv, adj, a_sn, num_peds, N, V, y, target, weights,
+                          losses, ws, scratch, grad_params, nullptr, events, n_events, stream);
 }
 
 }  // extern "C"

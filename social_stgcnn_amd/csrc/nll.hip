@@ -4,6 +4,7 @@
 // One workgroup per scene; the forward value follows the reference's operation order; the gradient
 // is the closed form of d(-log pdf)/d(pred) and is zero where the clamp is active.
 #include "common.hpp"
+#include "nll_elem.hpp"
 
 namespace stg {
 
@@ -23,45 +24,19 @@ __global__ __launch_bounds__(256) void nll_fwd_kernel(
     float acc = 0.f;
     for (int e = tid; e < P * V; e += blockDim.x) {
         const int p = e / V, v = e - p * V;
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
+        float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         if (v < vi) {
             const float *q = pn + p * p_sp + v * p_sv;
-            const float mx = q[0], my = q[p_sf], a = q[2 * p_sf], b = q[3 * p_sf], c = q[4 * p_sf];
             const float2 tg = *reinterpret_cast<const float2 *>(tn + (int64_t)e * 2);
-            const float dx = tg.x - mx, dy = tg.y - my;
-            const float sx = expf(a), sy = expf(b), rho = tanhf(c);
-            const float sxsy = sx * sy;
-            const float ux = dx / sx, uy = dy / sy;
-            const float cross = (rho * dx * dy) / sxsy;
-            const float z = ux * ux + uy * uy - 2.f * cross;
-            const float om = 1.f - rho * rho;
-            const float num = expf(-z / (2.f * om));
-            const float den = 2.f * 3.14159265358979323846f * (sxsy * sqrtf(om));
-            const float pdf = num / den;
-            // torch.clamp(min=eps) passes the gradient iff x >= eps.  A NaN pdf (tanh saturated to rho = +-1:
-            // 1 - rho^2 = 0, 0/0) is NOT clamped by torch: the loss and the element's five gradients become NaN
-            // there, so a diverged run shows up instead of training on a silent finite 46.05
-            const bool nan = pdf != pdf;
-            const bool live = pdf >= 1e-20f;
-            acc += nan ? pdf : -logf(live ? pdf : 1e-20f);
-            if (gn && nan) {
-                g0 = g1 = g2 = g3 = g4 = pdf;
-            } else if (gn && live) {
-                const float qq = (dx * dy) / sxsy;
-                g0 = -(dx / (sx * sx) - rho * dy / sxsy) / om;
-                g1 = -(dy / (sy * sy) - rho * dx / sxsy) / om;
-                g2 = 1.f - (ux * ux - rho * qq) / om;
-                g3 = 1.f - (uy * uy - rho * qq) / om;
-                g4 = -qq + z * rho / om - rho;
-            }
+            acc += nll_elem(q[0], q[p_sf], q[2 * p_sf], q[3 * p_sf], q[4 * p_sf], tg.x, tg.y, gn != nullptr, g);
         }
         if (gn) {
             const int64_t pv = (int64_t)P * V;
-            gn[e] = g0 * gs;
-            gn[pv + e] = g1 * gs;
-            gn[2 * pv + e] = g2 * gs;
-            gn[3 * pv + e] = g3 * gs;
-            gn[4 * pv + e] = g4 * gs;
+            gn[e] = g[0] * gs;
+            gn[pv + e] = g[1] * gs;
+            gn[2 * pv + e] = g[2] * gs;
+            gn[3 * pv + e] = g[3] * gs;
+            gn[4 * pv + e] = g[4] * gs;
         }
     }
     acc = wave_sum(acc);

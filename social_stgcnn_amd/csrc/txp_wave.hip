@@ -16,6 +16,7 @@
 #include "model_common.hpp"
 #include "stgcn_block.hpp"
 #include "txp_wave.hpp"
+#include "nll_elem.hpp"
 
 namespace stg {
 
@@ -484,6 +485,7 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, const float *
     float *slope_row = a.rows + (int64_t)n * (L.n_blk_params + L.n_txp) + L.n_blk_params;
     if (vi == 0) {                                     // empty scene: its row of small-parameter gradients is zero
         for (int e = lane; e < L.n_blk_params + L.n_txp; e += 64) slope_row[e - L.n_blk_params] = 0.f;
+        if (a.nll_target && lane == 0) a.nll_losses[n] = 0.f;
         return;
     }
     const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi;
@@ -509,6 +511,35 @@ __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, const float *
             const int vp = vi <= 1 ? 1 : (vi <= 2 ? 2 : (vi <= 4 ? 4 : (vi <= 8 ? 8 : (vi <= 16 ? 16 : (vi <= 32 ? 32 : 64)))));
             const int sh = __builtin_ctz(vp), rpi = 64 >> sh;       // rows per 64-lane pass
             const int sub = lane >> sh, w0 = lane & (vp - 1);
+            if (a.nll_target) {
+                // fused loss: a.dy is V_pred (N, 5, P, V); lanes are laid over (prediction step p, pedestrian w); the
+                // five gradients of (p, w) are rows f * P + p of the (C*P) x V array the chain starts from
+                const float *tn = a.nll_target + (int64_t)n * P * V * 2;
+                const float inv_cnt = 1.0f / (float)(P * vi);
+                const float gs = inv_cnt * (a.nll_weights ? a.nll_weights[n] : 1.f);
+                float lacc = 0.f;
+                for (int wb = 0; wb < vi; wb += 64) {
+                    const int w = wb + w0;
+                    const bool okw = w < vi;
+                    for (int p0 = 0; p0 < P; p0 += rpi) {
+                        const int p = p0 + sub;
+                        if (okw && p < P) {
+                            const float *q = dyn + (int64_t)p * V + w;
+                            const float2 tg = *reinterpret_cast<const float2 *>(tn + ((int64_t)p * V + w) * 2);
+                            float g[5];
+                            lacc += nll_elem(q[0], q[(int64_t)P * V], q[(int64_t)2 * P * V], q[(int64_t)3 * P * V],
+                                             q[(int64_t)4 * P * V], tg.x, tg.y, true, g);
+#pragma unroll
+                            for (int f = 0; f < C; ++f) {
+                                const int rc = f * P + p, ch = rc / C, h = rc - ch * C;
+                                dzb[ch * SC + (h + 1) * SW + (w + 1)] = g[f] * gs;
+                            }
+                        }
+                    }
+                }
+                lacc = wave_sum(lacc);
+                if (lane == 0) a.nll_losses[n] = lacc * inv_cnt;
+            } else
             for (int wb = 0; wb < vi; wb += 64) {                   // (vi > 64: a second column block)
                 const int w = wb + w0;
                 const bool okw = w < vi;

@@ -52,7 +52,12 @@ struct TxpBwdArgs {
     int64_t x_sn, x_sc, x_st, x_sv;
     const float *adj;      // (unused: no dx on this path, A is not needed)
     int64_t a_sn;
-    const float *dy;       // (N, C, P, V)
+    const float *dy;       // (N, C, P, V): dV_pred -- or, with nll_target, V_pred itself
+    // fused loss (stg_model_bwd_nll): the input stage computes d(sum_n w_n loss_n)/dV_pred from V_pred and the
+    // target instead of reading it, and writes the per-scene losses
+    const float *nll_target;   // (N, P, V, 2) or null
+    const float *nll_weights;  // (N) or null (all ones)
+    float *nll_losses;         // (N)
     const float *ws;
     int64_t ws_stride;
     float *dzg;            // [N][L][dz_slot(V)]   dz_l of the hidden layers for the weight-gradient GEMM

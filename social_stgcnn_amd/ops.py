@@ -301,6 +301,10 @@ class _FusedModel(torch.autograd.Function):
             # kernel bumps counter i for statistic row i < len(nbt): pass one pointer per BatchNorm.
             check(L.stg_bn_fold(ctypes.byref(desc), ptr(stats), ptr(peds), n, ptr(flat_buffers), arr, len(nbt),
                                 stream_ptr()), "stg_bn_fold")
+        if holder is not None:
+            # what a backward needs, for the trainer's fused loss + backward (backward_from_target)
+            holder._fwd_state = (desc, a_sn, dead, [tuple(p.shape) for p in params], flat_params, flat_buffers,
+                                 (x, adj_c, peds, ws)) if need_grad else None
         ctx.desc = desc
         ctx.a_sn = a_sn
         ctx.dead = dead
@@ -342,7 +346,53 @@ class _FusedModel(torch.autograd.Function):
             off += cnt
         if ctx.holder is not None:
             ctx.holder._flat_grad = grad       # the trainer all-reduces / applies this buffer directly
+            ctx.holder._fwd_state = None
         return (dx, None, None, None, None, None, None, None, None, None, *grads)
+
+
+def backward_from_target(holder, y, target, weights=None):
+    """Loss + backward of the fused forward `holder` (a model) just ran, in the backward's own launches
+    (stg_model_bwd_nll): per-scene bivariate losses (N,) are returned, the parameter gradients of
+    sum_n weights[n] * loss_n land in `holder._flat_grad` and in every live parameter's .grad (views of it).
+    Returns None -- nothing launched -- when the batch runs the workgroup-per-scene kernels: the caller then takes the
+    separate loss kernel + autograd backward."""
+    st = getattr(holder, "_fwd_state", None)
+    if st is None:
+        raise RuntimeError("backward_from_target: no fused forward with saved activations to start from")
+    desc, a_sn, dead, shapes, flat_params, flat_buffers, (x, adj_c, peds, ws) = st
+    L = lib()
+    n, cin, t, v = x.shape
+    if tuple(y.shape) != (n, 5, desc.t_pred, v) or not y.is_contiguous():
+        return None
+    target = target.to(torch.float32).contiguous()
+    if tuple(target.shape) != (n, desc.t_pred, v, 2):
+        raise ValueError("backward_from_target: target (N,P,V,2) expected, got %s" % (tuple(target.shape),))
+    w = weights.to(torch.float32).contiguous() if weights is not None else None
+    np_ = int(L.stg_model_param_count(ctypes.byref(desc)))
+    n_scratch = L.stg_model_bwd_scratch_floats(ctypes.byref(desc), n, v)
+    if n_scratch < 0:
+        check(int(n_scratch), "stg_model_bwd_scratch_floats")
+    slabs = torch.empty(int(n_scratch), device=x.device, dtype=torch.float32)
+    grad = torch.empty(np_, device=x.device, dtype=torch.float32)
+    losses = torch.empty(n, device=x.device, dtype=torch.float32)
+    sn, sc, st_, sv = x.stride()
+    ev = TIMER.events("model_bwd") if TIMER is not None else None
+    rc = L.stg_model_bwd_nll(ctypes.byref(desc), ptr(flat_params), ptr(flat_buffers), ptr(x), sn, sc, st_, sv, ptr(adj_c),
+                             a_sn, ptr(peds), n, v, ptr(y), ptr(target), ptr(w), ptr(losses), ptr(ws), ptr(slabs),
+                             ptr(grad), ev.arr if ev else None, ev.n if ev else 0, stream_ptr())
+    if rc == _lib.EUNSUPPORTED:
+        if ev is not None:
+            TIMER.calls["model_bwd"].pop()
+        return None
+    check(rc, "stg_model_bwd_nll")
+    off = 0
+    for i, (p, shp) in enumerate(zip(holder._tensors()[0], shapes)):
+        cnt = p.numel()
+        p.grad = None if i in dead else grad[off:off + cnt].view(shp)
+        off += cnt
+    holder._flat_grad = grad
+    holder._fwd_state = None
+    return losses
 
 
 def fused_model(x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, params, holder=None):

@@ -180,10 +180,14 @@ class Trainer:
         for p in model.parameters():
             p.grad = None
         y, _ = model(x, adj, num_peds)
-        # loss + its gradient w.r.t. V_pred in ONE kernel (per-scene weights folded in), then backward straight
-        # from dV_pred: no autograd graph through the loss, no separate scale / sum / expand kernels
-        losses, dy = ops.bivariate_nll_with_grad(y.detach(), target, num_peds, weights)
-        y.backward(dy)
+        # loss and backward in the backward's own launches (the input stage of the wave-per-scene kernel computes
+        # dV_pred from V_pred and the target: stg_model_bwd_nll); on the workgroup path: loss + its gradient w.r.t.
+        # V_pred in ONE kernel (per-scene weights folded in), then backward straight from dV_pred -- either way no
+        # autograd graph through the loss, no separate scale / sum / expand kernels
+        losses = ops.backward_from_target(model, y.detach(), target, weights) if y.requires_grad else None
+        if losses is None:
+            losses, dy = ops.bivariate_nll_with_grad(y.detach(), target, num_peds, weights)
+            y.backward(dy)
         if defer_tail:
             return None, losses, y.detach()
         total = ops.weighted_sum(losses, weights)

@@ -227,3 +227,53 @@ def test_step_tail_launch_equals_its_three_separate_launches(dev):
         else:
             assert float((got - ref).abs().max()) <= 2e-7 * max(1.0, float(ref.abs().max())), k
     assert int(out[0][1]["st_gcns.0.tcn.0.num_batches_tracked"]) == n - 1
+
+
+def test_fused_loss_backward_equals_loss_kernel_then_backward(dev):
+    """stg_model_bwd_nll (the backward's input stage computes dV_pred from V_pred and the target) against
+    stg_nll_fwd + stg_model_bwd on the same ragged batch (an empty scene, per-scene weights incl. a zero): per-scene
+    losses and every parameter gradient; and the workgroup path reports 'unsupported' so the trainer falls back."""
+    import bench
+    from social_stgcnn_amd import ops
+    from social_stgcnn_amd.model import social_stgcnn
+    n, v = 29, 11
+    obs_rel, target = bench.synth_scenes(n, v, 33)
+    nodes, adj = ops.adj_build(torch.from_numpy(obs_rel).to(dev))
+    x, tgt = nodes.permute(0, 3, 1, 2), torch.from_numpy(target).to(dev)
+    peds = torch.randint(1, v + 1, (n,), generator=torch.Generator().manual_seed(5)).to(torch.int32)
+    peds[7] = 0
+    peds = peds.to(dev)
+    w = torch.rand(n, generator=torch.Generator().manual_seed(6))
+    w[3] = 0.0
+    w = w.to(dev)
+    torch.manual_seed(12)
+    m = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3, pred_seq_len=12).to(dev).train()
+    y, _ = m(x, adj, peds)
+    losses = ops.backward_from_target(m, y.detach(), tgt, w)
+    assert losses is not None
+    fused = {k: (None if p.grad is None else p.grad.detach().cpu().clone()) for k, p in m.named_parameters()}
+    for p in m.parameters():
+        p.grad = None
+    state = {k: t.detach().clone() for k, t in m.state_dict().items()}
+    torch.manual_seed(12)
+    m2 = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3, pred_seq_len=12).to(dev).train()
+    y2, _ = m2(x, adj, peds)
+    l2, dy = ops.bivariate_nll_with_grad(y2.detach(), tgt, peds, w)
+    y2.backward(dy)
+    assert torch.allclose(losses.cpu(), l2.cpu(), rtol=2e-6, atol=1e-6)
+    assert float(losses[7]) == 0.0
+    for k, p in m2.named_parameters():
+        if p.grad is None:
+            assert fused[k] is None, k
+            continue
+        ref = p.grad.detach().cpu()
+        scale = max(1e-6, float(ref.abs().max()))
+        assert float((fused[k] - ref).abs().max()) <= 2e-6 * scale + 1e-9, k
+    del state
+    # workgroup-per-scene kernels: nothing fused, the caller is told so
+    ops.OPTIONS["wg_path"] = True
+    try:
+        y3, _ = m2(x, adj, peds)
+        assert ops.backward_from_target(m2, y3.detach(), tgt, w) is None
+    finally:
+        ops.OPTIONS["wg_path"] = False
