@@ -169,6 +169,28 @@ int stg_model_bwd_nll(const stg_model_desc *d, const float *params, const float 
                       int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj, int64_t a_sn, const int32_t *num_peds,
                       int N, int V, const float *y, const float *target, const float *weights, float *losses,
                       const float *ws, float *scratch, float *grad_params, void **events, int n_events, void *stream);
+
+/* The whole tail of a single-rank training step behind the fused loss + backward (train.py:58-76,197 + the
+ * running-statistics updates of model.py:114,123,140 for the scenes just forwarded): stg_model_bwd_nll whose last launch
+ * -- the fixed-order reduction of the partial gradients -- also applies SGD without clipping, p -= lr * grad (grad is
+ * still written), folds the forward's per-scene BatchNorm statistics into the running ones (= stg_bn_fold) and writes
+ * total[0] = sum_n weights[n] * losses[n] (= stg_weighted_sum), in extra workgroups of the same grid.  With
+ * clip_grad_norm_ the update depends on the norm of the complete gradient: use stg_model_bwd_nll + stg_train_tail.   */
+typedef struct stg_step_tail {
+    float *params;          /* the flat parameters (the same buffer as `params`), updated in place               */
+    const float *lr_dev;    /* learning rate in device memory (captured graphs follow StepLR), or NULL: use lr   */
+    float lr;
+    const float *stats;     /* per-scene batch statistics written by stg_model_fwd, or NULL: no fold             */
+    float *buffers;         /* running statistics, updated in place                                              */
+    int64_t *const *nbt;    /* num_batches_tracked counters (device pointers), n_bn of them, or NULL             */
+    int n_bn;
+    float *total;           /* out, 1 float, or NULL                                                             */
+} stg_step_tail;
+int stg_model_bwd_step(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
+                       int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj, int64_t a_sn, const int32_t *num_peds,
+                       int N, int V, const float *y, const float *target, const float *weights, float *losses,
+                       const float *ws, float *scratch, float *grad_params, const stg_step_tail *tail, void **events,
+                       int n_events, void *stream);
 /* Sequential-fold update of the BatchNorm running statistics with the per-scene statistics of a
  * batch, exactly as N successive reference forwards would (momentum update per scene,
  * model.py:114,123,140; SURVEY 7 'BatchNorm semantics').  Scenes with num_peds[n] == 0 are skipped.

@@ -55,6 +55,9 @@ _SIGNATURES = {
                             c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f]),
     "stg_model_bwd_nll": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_f, c_l, c_l, c_l, c_l, c_f, c_l, c_f, c_i, c_i,
                                 c_f, c_f, c_f, c_f, c_f, c_f, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f]),
+    "stg_model_bwd_step": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_f, c_l, c_l, c_l, c_l, c_f, c_l, c_f, c_i, c_i,
+                                 c_f, c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), c_i,
+                                 c_f]),
     "stg_bn_fold": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_i, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f]),
     "stg_nll_fwd": (c_i, [c_f, c_l, c_l, c_l, c_l, c_f, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_f]),
     "stg_nll_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f]),
@@ -105,6 +108,13 @@ def lib():
             raise RuntimeError("libstgcnn_hip.so ABI %d != binding ABI %d" % (h.stg_abi_version(), ABI_VERSION))
         _lib = h
     return _lib
+
+
+class StepTail(ctypes.Structure):
+    """stg_step_tail (include/stgcnn_hip.h)."""
+    _fields_ = [("params", ctypes.c_void_p), ("lr_dev", ctypes.c_void_p), ("lr", ctypes.c_float),
+                ("stats", ctypes.c_void_p), ("buffers", ctypes.c_void_p), ("nbt", ctypes.POINTER(ctypes.c_void_p)),
+                ("n_bn", ctypes.c_int), ("total", ctypes.c_void_p)]
 
 
 class HipEvents:

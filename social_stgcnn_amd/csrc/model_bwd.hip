@@ -28,6 +28,7 @@
 #include "stgcn_block.hpp"
 #include "txp_wave.hpp"
 #include "txp_wgrad.hpp"
+#include "tail_parts.hpp"
 
 namespace stg {
 
@@ -276,8 +277,34 @@ struct ReduceArgs {
 
 // One workgroup owns 8 consecutive parameters; its 32 lane-groups stride over the slab rows (up to 2048 of
 // them), 4 independent row loads in flight each; the 32 partial sums meet in LDS in a fixed order.
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceArgs a) {
+// The step tail (stg_model_bwd_step) rides in the same launch: the reducing workgroups also apply SGD to their eight
+// parameters, workgroups behind them fold the BatchNorm statistics (one each) and sum the reported loss.
+struct TailArgs {
+    float *params;              // null: plain reduction
+    const float *lr_dev;
+    float lr;
+    const float *stats, *losses, *weights;
+    const int32_t *num_peds;
+    float *buffers, *total;
+    NbtPtrs nbt;
+    int n_reduce, n_buffers, N, stat_floats;
+    float momentum;
+};
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceArgs a, const TailArgs t_) {
     __shared__ float part[32][8];
+    if ((int)blockIdx.x >= t_.n_reduce) {
+        float *acc_s = &part[0][0];                      // 256 floats
+        __shared__ float dec_s[256];
+        __shared__ int cnt_s[256];
+        const int b = (int)blockIdx.x - t_.n_reduce;
+        if (b < t_.n_buffers)
+            bn_fold_body<256>(b, t_.stats, t_.num_peds, t_.N, t_.stat_floats, t_.momentum, t_.buffers, t_.nbt, acc_s, dec_s,
+                              cnt_s);
+        else if (t_.total)
+            weighted_sum_body(t_.losses, t_.weights, t_.N, t_.total, acc_s);
+        return;
+    }
     const int col = threadIdx.x & 7, grp = threadIdx.x >> 3;
     const int p = blockIdx.x * 8 + col;
     float s = 0.f;
@@ -312,6 +339,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceArgs a) {
 #pragma unroll
         for (int g = 0; g < 32; ++g) t += part[g][col];
         a.grad[p] = t;
+        if (t_.params) t_.params[p] -= (t_.lr_dev ? t_.lr_dev[0] : t_.lr) * t;
     }
 }
 
@@ -410,8 +438,8 @@ int64_t stg_model_bwd_scratch_floats(const stg_model_desc *d, int N, int V) {
 static int model_bwd_impl(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
                           int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj, int64_t a_sn,
                           const int32_t *num_peds, int N, int V, const float *dy, const float *nll_target,
-                          const float *nll_weights, float *nll_losses, const float *ws, float *scratch,
-                          float *grad_params, float *dx, void **events, int n_events, void *stream) {
+                          const float *nll_weights, float *nll_losses, const stg_step_tail *tail, const float *ws,
+                          float *scratch, float *grad_params, float *dx, void **events, int n_events, void *stream) {
     using namespace stg;
     BwdArgs a{};
     const int rc = make_layout(d, &a.lay);
@@ -554,7 +582,20 @@ static int model_bwd_impl(const stg_model_desc *d, const float *params, const fl
                                          wgrad_row_len(l), cv.slab2 + wgrad_slab_base(l, wg.rows)};
         }
     }
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((L.n_params + 7) / 8), dim3(256), 0, st, r);
+    TailArgs ta{};
+    ta.n_reduce = (L.n_params + 7) / 8;
+    int extra = 0;
+    if (tail) {
+        ta.params = tail->params; ta.lr_dev = tail->lr_dev; ta.lr = tail->lr;
+        ta.stats = tail->stats; ta.buffers = tail->buffers; ta.total = tail->total;
+        ta.losses = nll_losses; ta.weights = nll_weights; ta.num_peds = num_peds;
+        ta.N = N; ta.stat_floats = L.stat_floats; ta.momentum = d->bn_momentum;
+        ta.n_buffers = (tail->stats && N > 0) ? L.n_buffers : 0;
+        ta.nbt.n = tail->nbt ? tail->n_bn : 0;
+        for (int k = 0; k < ta.nbt.n; ++k) ta.nbt.p[k] = tail->nbt[k];
+        extra = ta.n_buffers + 1;
+    }
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ta.n_reduce + extra), dim3(256), 0, st, r, ta);
     STG_LAUNCH_CHECK("stg_model_bwd: reduce_slabs");
     evl.mark();
     evl.finish();
@@ -566,7 +607,7 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
                   int N, int V, const float *dy, const float *ws, float *scratch, float *grad_params, float *dx,
                   void **events, int n_events, void *stream) {
     return model_bwd_impl(d, params, buffers, x, x_sn, x_sc, x_st, x_sv, adj, a_sn, num_peds, N, V, dy, nullptr, nullptr,
-                          nullptr, ws, scratch, grad_params, dx, events, n_events, stream);
+                          nullptr, nullptr, ws, scratch, grad_params, dx, events, n_events, stream);
 }
 
 int stg_model_bwd_nll(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
@@ -575,7 +616,20 @@ int stg_model_bwd_nll(const stg_model_desc *d, const float *params, const float 
                       const float *ws, float *scratch, float *grad_params, void **events, int n_events, void *stream) {
     if (!target || !losses || (N > 0 && !y)) return stg::fail(STG_EINVAL, "stg_model_bwd_nll: null pointer");
     return model_bwd_impl(d, params, buffers, x, x_sn, x_sc, x_st, x_sv, adj, a_sn, num_peds, N, V, y, target, weights,
-                          losses, ws, scratch, grad_params, nullptr, events, n_events, stream);
+                          losses, nullptr, ws, scratch, grad_params, nullptr, events, n_events, stream);
+}
+
+int stg_model_bwd_step(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
+                       int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj, int64_t a_sn, const int32_t *num_peds,
+                       int N, int V, const float *y, const float *target, const float *weights, float *losses,
+                       const float *ws, float *scratch, float *grad_params, const stg_step_tail *tail, void **events,
+                       int n_events, void *stream) {
+    if (!target || !losses || (N > 0 && !y)) return stg::fail(STG_EINVAL, "stg_model_bwd_step: null pointer");
+    if (!tail || !tail->params || (tail->stats && !tail->buffers) || tail->n_bn < 0 || tail->n_bn > 3 * STG_MAX_BLOCKS)
+        return stg::fail(STG_EINVAL, "stg_model_bwd_step: bad tail");
+    if (N == 0) return STG_EUNSUPPORTED;               // (an empty batch has no backward launch to ride on)
+    return model_bwd_impl(d, params, buffers, x, x_sn, x_sc, x_st, x_sv, adj, a_sn, num_peds, N, V, y, target, weights,
+                          losses, tail, ws, scratch, grad_params, nullptr, events, n_events, stream);
 }
 
 }  // extern "C"

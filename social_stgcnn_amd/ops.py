@@ -350,12 +350,16 @@ class _FusedModel(torch.autograd.Function):
         return (dx, None, None, None, None, None, None, None, None, None, *grads)
 
 
-def backward_from_target(holder, y, target, weights=None):
+def backward_from_target(holder, y, target, weights=None, step=None):
     """Loss + backward of the fused forward `holder` (a model) just ran, in the backward's own launches
     (stg_model_bwd_nll): per-scene bivariate losses (N,) are returned, the parameter gradients of
     sum_n weights[n] * loss_n land in `holder._flat_grad` and in every live parameter's .grad (views of it).
     Returns None -- nothing launched -- when the batch runs the workgroup-per-scene kernels: the caller then takes the
-    separate loss kernel + autograd backward."""
+    separate loss kernel + autograd backward.
+
+    step = (pending_bn, lr, lr_dev): the rest of a single-rank training step rides in the same launches
+    (stg_model_bwd_step: SGD without clipping on the flat parameters, the BatchNorm fold of `pending_bn` -- what a
+    forward with a deferred fold left behind -- and the reported loss); returns (losses, total) then."""
     st = getattr(holder, "_fwd_state", None)
     if st is None:
         raise RuntimeError("backward_from_target: no fused forward with saved activations to start from")
@@ -377,14 +381,30 @@ def backward_from_target(holder, y, target, weights=None):
     losses = torch.empty(n, device=x.device, dtype=torch.float32)
     sn, sc, st_, sv = x.stride()
     ev = TIMER.events("model_bwd") if TIMER is not None else None
-    rc = L.stg_model_bwd_nll(ctypes.byref(desc), ptr(flat_params), ptr(flat_buffers), ptr(x), sn, sc, st_, sv, ptr(adj_c),
-                             a_sn, ptr(peds), n, v, ptr(y), ptr(target), ptr(w), ptr(losses), ptr(ws), ptr(slabs),
-                             ptr(grad), ev.arr if ev else None, ev.n if ev else 0, stream_ptr())
+    total = None
+    if step is None:
+        rc = L.stg_model_bwd_nll(ctypes.byref(desc), ptr(flat_params), ptr(flat_buffers), ptr(x), sn, sc, st_, sv,
+                                 ptr(adj_c), a_sn, ptr(peds), n, v, ptr(y), ptr(target), ptr(w), ptr(losses), ptr(ws),
+                                 ptr(slabs), ptr(grad), ev.arr if ev else None, ev.n if ev else 0, stream_ptr())
+    else:
+        pending_bn, lr, lr_dev = step
+        total = torch.empty(1, device=x.device, dtype=torch.float32)
+        tail = _lib.StepTail()
+        tail.params, tail.lr_dev, tail.lr = ptr(flat_params), ptr(lr_dev), float(lr)
+        tail.total = ptr(total)
+        if pending_bn is not None:
+            _, stats, _, _, bn_buffers, nbt = pending_bn
+            arr = (ctypes.c_void_p * len(nbt))(*[b.data_ptr() for b in nbt])
+            tail.stats, tail.buffers, tail.nbt, tail.n_bn = ptr(stats), ptr(bn_buffers), arr, len(nbt)
+        rc = L.stg_model_bwd_step(ctypes.byref(desc), ptr(flat_params), ptr(flat_buffers), ptr(x), sn, sc, st_, sv,
+                                  ptr(adj_c), a_sn, ptr(peds), n, v, ptr(y), ptr(target), ptr(w), ptr(losses), ptr(ws),
+                                  ptr(slabs), ptr(grad), ctypes.addressof(tail), ev.arr if ev else None,
+                                  ev.n if ev else 0, stream_ptr())
     if rc == _lib.EUNSUPPORTED:
         if ev is not None:
             TIMER.calls["model_bwd"].pop()
         return None
-    check(rc, "stg_model_bwd_nll")
+    check(rc, "stg_model_bwd_nll" if step is None else "stg_model_bwd_step")
     off = 0
     for i, (p, shp) in enumerate(zip(holder._tensors()[0], shapes)):
         cnt = p.numel()
@@ -392,7 +412,7 @@ def backward_from_target(holder, y, target, weights=None):
         off += cnt
     holder._flat_grad = grad
     holder._fwd_state = None
-    return losses
+    return losses if step is None else (losses, total[0])
 
 
 def fused_model(x, adj, num_peds, desc, flat_params, flat_buffers, nbt, dead, params, holder=None):

@@ -206,6 +206,31 @@ class Trainer:
         """forward_backward + [ONE all-reduce: gradient and BatchNorm fold across ranks] + SGD update.  No host
         synchronisation anywhere: the scene counts the fold needs travel inside the collective."""
         model = self.model
+        if self.world == 1 and self.clip_grad is None and model.training:
+            # no clipping: the whole tail (SGD, running-statistics fold, reported loss) rides in the backward's last
+            # launch (stg_model_bwd_step) -- when the batch runs the wave-per-scene kernels
+            for p in model.parameters():
+                p.grad = None
+            model._defer_bn_fold, model._pending_bn = True, None
+            try:
+                y, _ = model(x, adj, num_peds)
+            finally:
+                model._defer_bn_fold = False
+            flat_p = model.flat_parameters()
+            res = None
+            if y.requires_grad and model._pending_bn is not None:
+                res = ops.backward_from_target(model, y.detach(), target, weights,
+                                               step=(model._pending_bn, self.lr, self._lr_tensor(flat_p.device)))
+            if res is not None:
+                model._pending_bn = None
+                return res[1], res[0], y.detach()
+            # workgroup path: loss kernel + autograd backward + the tail launch
+            losses, dy = ops.bivariate_nll_with_grad(y.detach(), target, num_peds, weights)
+            y.backward(dy)
+            total = ops.train_tail(model._pending_bn, losses, weights, flat_p, self._flat_grad(), self.lr, None,
+                                   self._lr_tensor(flat_p.device))
+            model._pending_bn = None
+            return total, losses, y.detach()
         if self.world == 1:
             # forward + loss + backward, then ONE tail launch: running-statistics fold, reported loss, clip + SGD
             model._defer_bn_fold, model._pending_bn = model.training, None

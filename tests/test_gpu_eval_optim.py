@@ -190,8 +190,10 @@ def test_trainer_clip_and_schedule_follow_the_reference_loop(dev):
         assert np.abs(a - b).max() < 2e-5 * max(1.0, np.abs(b).max()), k
 
 
-def test_step_tail_launch_equals_its_three_separate_launches(dev):
-    """stg_train_tail (BatchNorm fold + reported loss + clip/SGD in ONE launch, what Trainer.step runs on one rank)
+@pytest.mark.parametrize("clip", (0.01, None))
+def test_step_tail_launch_equals_its_three_separate_launches(dev, clip):
+    """stg_train_tail (BatchNorm fold + reported loss + clip/SGD in ONE launch, what Trainer.step runs on one rank with
+    clipping) and stg_model_bwd_step (no clipping: the tail rides in the backward's reduction launch)
     against the module-API sequence: forward with its own stg_bn_fold, stg_weighted_sum, stg_optim_step -- same
     inputs, ragged scenes with an empty one; running statistics and parameters within 1 ulp of the summation order."""
     import bench
@@ -210,7 +212,7 @@ def test_step_tail_launch_equals_its_three_separate_launches(dev):
     for fused in (True, False):
         torch.manual_seed(9)
         m = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3, pred_seq_len=12).to(dev).train()
-        tr = Trainer(m, lr=0.05, clip_grad=0.01)
+        tr = Trainer(m, lr=0.05, clip_grad=clip)
         if fused:
             total, _, _ = tr.step(x, adj, tgt, peds, w)
         else:
