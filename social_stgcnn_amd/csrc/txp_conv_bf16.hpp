@@ -48,11 +48,11 @@ constexpr int kWpDwords = kWpVecs * 64 * 4;   // dwords of one prepared layer
 __host__ __device__ inline int sw(int vi) { return vi + 1; }
 __host__ __device__ inline int row_bytes(int vi) { return sw(vi) * kPosBytes; }
 // bytes of one piece image: 8 row slots + the leading border position + 3 positions of read overrun, == 128 (mod 256)
-__host__ __device__ inline int plane_bytes(int vi) {
-    const int r = (kSlots * sw(vi) + 4) * kPosBytes;
+__host__ __device__ inline int plane_bytes(int vi, int slots = kSlots) {
+    const int r = (slots * sw(vi) + 4) * kPosBytes;
     return r + ((128 - r % 256) + 256) % 256;
 }
-__host__ __device__ inline int image_bytes(int vi) { return 3 * plane_bytes(vi); }
+__host__ __device__ inline int image_bytes(int vi, int slots = kSlots) { return 3 * plane_bytes(vi, slots); }
 // byte offset (within a piece image) of the record of (row slot, column)
 __host__ __device__ inline int pos_off(int vi, int slot, int col) { return (slot * sw(vi) + col + 1) * kPosBytes; }
 
@@ -130,10 +130,10 @@ struct LaneGeom {
     unsigned c1, d2;     // byte offsets: read set 1 = base + c1 (piece + half-chunk), read set 2 = set 1 + d2
     int PL, RB;
 };
-__device__ __forceinline__ LaneGeom lane_geom(int vi) {
+__device__ __forceinline__ LaneGeom lane_geom(int vi, int slots = kSlots) {
     const int kg = (threadIdx.x & 63) >> 4;
     LaneGeom g;
-    g.PL = plane_bytes(vi);
+    g.PL = plane_bytes(vi, slots);
     g.RB = row_bytes(vi);
     g.c1 = ((kg & 1) ? g.PL : 0) + (kg >> 1) * 16;
     g.d2 = (kg & 1) ? g.PL : 0;
@@ -227,15 +227,57 @@ __device__ __forceinline__ f32x4 mma(const u32x4 &a, const u32x2 &b0, const u32x
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// 12 MFMAs of groups [G0, G0 + 4), dealt round-robin to four accumulator chains: a 4-pass MFMA never issues right
-// behind the one it depends on
-template <int G0>
-__device__ __forceinline__ void mma_groups(const u32x4 (&w)[kWpVecs], const BRegs &b, f32x4 (&acc)[4]) {
+// 12 MFMAs of groups [G0, G0 + 4), dealt round-robin to NC accumulator chains (a dependent 4-pass MFMA issues back to
+// back at full rate -- tools/micro/mfma_chain.hip -- so NC only trades registers against the final adds)
+template <int G0, int NC>
+__device__ __forceinline__ void mma_groups(const u32x4 (&w)[kWpVecs], const BRegs &b, f32x4 (&acc)[NC]) {
 #pragma unroll
     for (int g = G0; g < G0 + 4; ++g) {
-        acc[(3 * g + 0) & 3] = mma(w[3 * g + 0], b.s1[g][0], b.s1[g][1], acc[(3 * g + 0) & 3]);
-        acc[(3 * g + 1) & 3] = mma(w[3 * g + 1], b.s1[g][0], b.s1[g][1], acc[(3 * g + 1) & 3]);
-        acc[(3 * g + 2) & 3] = mma(w[3 * g + 2], b.s2[g][0], b.s2[g][1], acc[(3 * g + 2) & 3]);
+        acc[(3 * g + 0) % NC] = mma(w[3 * g + 0], b.s1[g][0], b.s1[g][1], acc[(3 * g + 0) % NC]);
+        acc[(3 * g + 1) % NC] = mma(w[3 * g + 1], b.s1[g][0], b.s1[g][1], acc[(3 * g + 1) % NC]);
+        acc[(3 * g + 2) % NC] = mma(w[3 * g + 2], b.s2[g][0], b.s2[g][1], acc[(3 * g + 2) % NC]);
+    }
+}
+
+// ---- half-tile form (32 operand registers instead of 64): groups 4H .. 4H+3 at a time ------------------------------
+struct BHalf {
+    u32x2 s1[4][2], s2[4][2];
+};
+template <int H>
+__device__ __forceinline__ void load_b_half(unsigned lds_base, const Tile &t, BHalf &b) {
+#define STG_CV_G(i, bi, imm)                                       \
+    read16<imm>(lds_base + t.r1[bi], b.s1[i][0], b.s1[i][1]);     \
+    read16<imm>(lds_base + t.r2[bi], b.s2[i][0], b.s2[i][1]);
+    if (H == 0) {
+        STG_CV_G(0, 0, 0)
+        STG_CV_G(1, 0, 32)
+        STG_CV_G(2, 3, 0)
+        STG_CV_G(3, 1, 16)
+    } else {
+        STG_CV_G(0, 1, 48)
+        STG_CV_G(1, 2, 0)
+        STG_CV_G(2, 2, 32)
+        STG_CV_G(3, 2, 64)
+    }
+#undef STG_CV_G
+}
+__device__ __forceinline__ void wait_half(BHalf &b) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(b.s1[0][0]), "+v"(b.s1[0][1]), "+v"(b.s2[0][0]), "+v"(b.s2[0][1]), "+v"(b.s1[1][0]),
+                   "+v"(b.s1[1][1]), "+v"(b.s2[1][0]), "+v"(b.s2[1][1]), "+v"(b.s1[2][0]), "+v"(b.s1[2][1]),
+                   "+v"(b.s2[2][0]), "+v"(b.s2[2][1]), "+v"(b.s1[3][0]), "+v"(b.s1[3][1]), "+v"(b.s2[3][0]),
+                   "+v"(b.s2[3][1])
+                 :
+                 : "memory");
+}
+template <int H>
+__device__ __forceinline__ void mma_half(const u32x4 (&w)[kWpVecs], const BHalf &b, f32x4 &acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = 4 * H + i;
+        acc = mma(w[3 * g + 0], b.s1[i][0], b.s1[i][1], acc);
+        acc = mma(w[3 * g + 1], b.s1[i][0], b.s1[i][1], acc);
+        acc = mma(w[3 * g + 2], b.s2[i][0], b.s2[i][1], acc);
     }
 }
 
@@ -279,10 +321,10 @@ __device__ __forceinline__ void conv_tiles(const u32x4 (&w)[kWpVecs], const f32x
         if (DBG & 16) __builtin_amdgcn_s_barrier();
         wait_groups<15, 0>(b, q);       // reads issued in order, <= 15 outstanding: groups 0..3 have landed
         STG_CV_STAMP(4);
-        if (!(DBG & 4)) mma_groups<0>(w, b, acc);
+        if (!(DBG & 4)) mma_groups<0, 4>(w, b, acc);
         STG_CV_STAMP(5);
         wait_groups<0, 4>(b, q);
-        if (!(DBG & 4)) mma_groups<4>(w, b, acc);
+        if (!(DBG & 4)) mma_groups<4, 4>(w, b, acc);
         if (DBG & 4) acc[1] = f32x4{__uint_as_float(b.s1[0][0].x ^ b.s2[7][1].y), __uint_as_float(b.s1[3][0].x), 0.f, __uint_as_float(w[5].x ^ w[23].y)};
         cp = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         STG_CV_STAMP(6);

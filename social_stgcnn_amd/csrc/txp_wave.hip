@@ -17,6 +17,7 @@
 #include "stgcn_block.hpp"
 #include "txp_wave.hpp"
 #include "nll_elem.hpp"
+#include "txp_conv_bf16.hpp"
 
 namespace stg {
 
@@ -459,17 +460,19 @@ __device__ __forceinline__ void dgrad_layer(const float (&wreg)[27], const float
 // [C][T+2][vi] (140 vi floats <= plane_slot + 60 V); db1 reuses D.  Small-parameter gradients leave as the scene's own
 // row (stores, no atomics): reduce_slabs_kernel sums the rows in a fixed order.
 __device__ __forceinline__ void txp_bwd_block_tail(const TxpBwdArgs &a, const float *blk_params, int n, int vi,
-                                                   float *dzb, float *dcur, ptab_t *ptab, float *tot, float *slope_row) {
+                                                   float *dzb, float *dcur, ptab_t *ptab, float *tot, float *slope_row,
+                                                   bool d_ready = false) {
     const ModelLayout &L = a.lay;
     const int lane = threadIdx.x & 63;
     for (int e = L.L + lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;       // dead slopes (layers >= L)
     if (STG_SKIP(a, 4)) return;
     float *D = dzb, *H1 = dzb + C * T * vi, *DH2 = H1 + C * (T + 2) * vi;
     // v.view(N, T, C, V) (model.py:187) backwards: plane (ch, row) is flat f = ch*C + row = c*T + t of the block output
-    for (int f = 0; f < C * T; ++f) {
-        const int ch = f / C, row = f - ch * C;
-        for (int w = lane; w < vi; w += 64) D[f * vi + w] = dcur[(row * vi + w) * P + ch];
-    }
+    if (!d_ready)
+        for (int f = 0; f < C * T; ++f) {
+            const int ch = f / C, row = f - ch * C;
+            for (int w = lane; w < vi; w += 64) D[f * vi + w] = dcur[(row * vi + w) * P + ch];
+        }
     __builtin_amdgcn_wave_barrier();
     float *row = slope_row - L.n_blk_params;
     stgcn_block_bwd<Cfg::CIN0, 0, false>(a, blk_params, L.blk[0], n, vi, D, H1, DH2, D, nullptr, tot, row,
@@ -859,6 +862,247 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) void txp_bwd_wave_kerne
 }
 
 // ------------------------------------------------------------------------------------------
+// backward, exact-bf16 variant (x6): the input-gradient GEMMs on v_mfma_f32_16x16x32_bf16 with three-piece operands
+// ------------------------------------------------------------------------------------------
+// txp_conv_bf16.hpp: dz_l lives in LDS as three position-major bf16 piece images (x = x_h + x_m + x_l exactly), the six
+// products that reach 2^-24 are accumulated in fp32 -- the same accuracy class as the fp32 MFMA, but 24 MFMAs of 16
+// matrix-pipe cycles per tile that run BESIDE the VALU instead of 27 fp32 MFMAs that hold the SIMD's VALU port for 32
+// cycles each (tools/micro/mfma_valu_overlap.hip).  The running input gradient d(a_l) stays in REGISTERS: a lane owns
+// the same (position, channel quad) of every tile in every layer (<= 10 tiles for V_n <= 32), which is also the quad
+// structure of the saved z_l / dz_l arrays -- no LDS copy of it, no position table in the dz construction.
+constexpr int kX6Tiles = 10;                          // 16-position tiles of a scene of <= 32 pedestrians
+constexpr int kX6Slots = 7;                           // row slots of the dz image: borders + C interior rows
+__host__ __device__ inline int bwd6_region_floats(int v) {
+    const int img = cv::image_bytes(v, kX6Slots) / 4, tail = (2 * C * (T + 2) + C * T) * v;    // (the block tail's arrays)
+    return ((img > tail ? img : tail) + 3) & ~3;
+}
+
+__global__ __launch_bounds__(64) void txp_bwd_prep_kernel(const ModelLayout L, const float *__restrict__ params,
+                                                          unsigned *__restrict__ wp) {
+    // block = (layer l, operand vector v); layer L.L = the output conv.  A operands of
+    // d in[ci][pos] = sum W[co][ci][2-kh][2-kw] dz[co][pos+tap]
+    const int l = blockIdx.x / cv::kWpVecs, v = blockIdx.x - l * cv::kWpVecs, lane = threadIdx.x;
+    const int cinl = l == 0 ? T : P;
+    const float *W = params + (l < L.L ? L.txp_w[l] : L.out_w);
+    auto wf = [&](int m, int ch, int kh, int kw) -> float {
+        return m < cinl ? W[(ch * cinl + m) * 9 + (2 - kh) * 3 + (2 - kw)] : 0.f;
+    };
+    unsigned d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        d[q] = (unsigned)cv::wp_value(wf, v / 3, v % 3, lane, 2 * q) |
+               ((unsigned)cv::wp_value(wf, v / 3, v % 3, lane, 2 * q + 1) << 16);
+    reinterpret_cast<cv::u32x4 *>(wp + (int64_t)l * cv::kWpDwords)[v * 64 + lane] = cv::u32x4{d[0], d[1], d[2], d[3]};
+}
+
+__device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const float *blk_params, int n, float *region,
+                                                 ptab_t *ptab, float *tot) {
+    const ModelLayout &L = a.lay;
+    const int V = a.V, lane = threadIdx.x & 63, nq = lane & 15, kq = lane >> 4;
+    int vi = a.num_peds ? a.num_peds[n] : V;
+    vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
+    float *slope_row = a.rows + (int64_t)n * (L.n_blk_params + L.n_txp) + L.n_blk_params;
+    if (vi == 0) {                                     // empty scene: its row of small-parameter gradients is zero
+        for (int e = lane; e < L.n_blk_params + L.n_txp; e += 64) slope_row[e - L.n_blk_params] = 0.f;
+        if (a.nll_target && lane == 0) a.nll_losses[n] = 0.f;
+        return;
+    }
+    const int npos = C * vi, ntiles = (npos + 15) >> 4;
+    const float *Pm = a.params;
+    const float *wsn = a.ws + n * a.ws_stride;
+    const float *dyn = a.dy + (int64_t)n * (C * P) * V;
+    unsigned char *img = reinterpret_cast<unsigned char *>(region);
+    const cv::LaneGeom lg = cv::lane_geom(vi, kX6Slots);
+    {
+        uint4 *z4 = reinterpret_cast<uint4 *>(img);
+        for (int e = lane; e < (3 * lg.PL) >> 4; e += 64) z4[e] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    build_ptab(ptab, vi);
+    __builtin_amdgcn_wave_barrier();
+    // this lane's position of every tile: byte offset of its record quad in the image (interior row 0 = slot 1), -1 past
+    // the scene's last position
+    auto rec_of = [&](int t) -> int {
+        const int p = 16 * t + nq;
+        const unsigned hw = ptab[p < npos ? p : 0];
+        return (p < npos && kq < 3) ? cv::pos_off(vi, 1 + (int)(hw >> 8), (int)(hw & 0xffu)) + 8 * kq : -1;
+    };
+    f32x4 dcur[kX6Tiles];
+#pragma unroll
+    for (int t = 0; t < kX6Tiles; ++t) dcur[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int l = L.L; l >= 0; --l) {
+        // ---- dz_l -> the piece images (and position-major fp32 to HBM for the weight-gradient GEMM) -----------------
+        float *dzo = a.dzg + ((int64_t)n * (L.L + 1) + l) * dz_slot(V);
+        if (STG_SKIP(a, 512) || (l == L.L && STG_SKIP(a, 2048)) || (l != L.L && STG_SKIP(a, 4096))) {
+        } else if (l == L.L) {
+            // dz of the output conv is dV_pred: row rc = f * P + p of the (C*P) x V array is channel rc / C, plane row
+            // rc % C.  Lanes are laid over (row or prediction step, pedestrian) with the row length rounded up to a power
+            // of two; every value is split and dropped into its record as three 2-byte stores.
+            const int vp = vi <= 1 ? 1 : (vi <= 2 ? 2 : (vi <= 4 ? 4 : (vi <= 8 ? 8 : (vi <= 16 ? 16 : 32))));
+            const int sh = __builtin_ctz(vp), rpi = 64 >> sh;
+            const int sub = lane >> sh, w = lane & (vp - 1);
+            const bool okw = w < vi;
+            auto put1 = [&](int rc, float g) {
+                const int ch = rc / C, h = rc - ch * C;
+                float ph, pm, pl;
+                cv::split3(g, ph, pm, pl);
+                unsigned char *q = img + cv::pos_off(vi, 1 + h, w) + 2 * ch;
+                *reinterpret_cast<unsigned short *>(q) = (unsigned short)cv::hi16(ph);
+                *reinterpret_cast<unsigned short *>(q + lg.PL) = (unsigned short)cv::hi16(pm);
+                *reinterpret_cast<unsigned short *>(q + 2 * lg.PL) = (unsigned short)cv::hi16(pl);
+            };
+            if (a.nll_target) {
+                const float *tn = a.nll_target + (int64_t)n * P * V * 2;
+                const float inv_cnt = 1.0f / (float)(P * vi);
+                const float gs = inv_cnt * (a.nll_weights ? a.nll_weights[n] : 1.f);
+                float lacc = 0.f;
+                for (int p0 = 0; p0 < P; p0 += rpi) {
+                    const int p = p0 + sub;
+                    if (okw && p < P) {
+                        const float *q = dyn + (int64_t)p * V + w;
+                        const float2 tg = *reinterpret_cast<const float2 *>(tn + ((int64_t)p * V + w) * 2);
+                        float g[5];
+                        lacc += nll_elem(q[0], q[(int64_t)P * V], q[(int64_t)2 * P * V], q[(int64_t)3 * P * V],
+                                         q[(int64_t)4 * P * V], tg.x, tg.y, true, g);
+#pragma unroll
+                        for (int f = 0; f < C; ++f) put1(f * P + p, g[f] * gs);
+                    }
+                }
+                lacc = wave_sum(lacc);
+                if (lane == 0) a.nll_losses[n] = lacc * inv_cnt;
+            } else {
+                constexpr int U = 4;
+                for (int r0 = 0; r0 < C * P; r0 += rpi * U) {
+                    float dv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int row = r0 + u * rpi + sub;
+                        dv[u] = (okw && row < C * P) ? dyn[(int64_t)row * V + w] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int row = r0 + u * rpi + sub;
+                        if (okw && row < C * P) put1(row, dv[u]);
+                    }
+                }
+            }
+            // the position-major fp32 copy for the weight-gradient GEMM: the lane's quad of every tile, read back from
+            // the pieces (h + m + l is exact), one 16-byte store each -- a scattered 4-byte store per value cost 20 us
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < kX6Tiles; ++t) {
+                const int rc_ = rec_of(t);
+                if (rc_ >= 0) reinterpret_cast<f32x4 *>(dzo)[(16 * t + nq) * 3 + kq] = cv::get4(img, (unsigned)rc_, lg.PL);
+            }
+        } else {
+            // dz_l = d(a_{l+1}) * prelu'(z_l): z_l and dz_l are position-major [pos][12] in HBM, the lane's quad of tile t
+            // is vector (16 t + n) * 3 + kq
+            const float *zl = wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V;
+            const float alpha = Pm[L.prelus + l];
+            float slope_acc = 0.f;
+            // all ten quads of z_l in flight at once (the weight registers are dead here): one HBM latency per layer.
+            // (Requesting them BEFORE the previous layer's MFMAs needs 40 more live registers there and spilled; a
+            // never-awaited "touch" load into a dead register is not an option either -- the register is reused
+            // while the load is in flight and the late write-back corrupts its new owner.)
+            f32x4 zv[kX6Tiles];
+            int rec[kX6Tiles];
+#pragma unroll
+            for (int t = 0; t < kX6Tiles; ++t) rec[t] = rec_of(t);
+#pragma unroll
+            for (int t = 0; t < kX6Tiles; ++t)
+                zv[t] = rec[t] >= 0 ? reinterpret_cast<const f32x4 *>(zl)[(16 * t + nq) * 3 + kq] : f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int t = 0; t < kX6Tiles; ++t) {
+                if (rec[t] >= 0) {
+                    f32x4 dzv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = zv[t][r], d = dcur[t][r];
+                        float dz = d;
+                        if (!(z > 0.f)) {
+                            dz = alpha * d;
+                            slope_acc = fmaf(d, z, slope_acc);
+                        }
+                        dzv[r] = dz;
+                    }
+                    cv::put4(img, (unsigned)rec[t], lg.PL, dzv);
+                    reinterpret_cast<f32x4 *>(dzo)[(16 * t + nq) * 3 + kq] = dzv;
+                }
+            }
+            slope_acc = wave_sum(slope_acc);
+            if (lane == 0) slope_row[l] = slope_acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- d(a_l) = conv_transpose(dz_l, W_l) [+ d(a_{l+1}) through the residual of the hidden layers] ----------------
+        if (!STG_SKIP(a, 1024)) {
+            cv::u32x4 w[cv::kWpVecs];
+            cv::load_wp(a.wp + (int64_t)l * cv::kWpDwords, w);
+            const unsigned lds_base = (unsigned)(uintptr_t)img;
+            const bool keep = l != L.L && l != 0;       // d(a_l) += d(a_{l+1}) (a_{l+1} = prelu(z_l) + a_l for 1 <= l < L)
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < kX6Tiles; ++t) {
+                if (t < ntiles) {
+                    const cv::Tile tl = cv::tile_of<1>(t, ptab, npos, lg, vi);
+                    // two half-tiles through ONE 32-register operand set (96 weight + 40 gradient registers are live):
+                    // the second half's reads wait for the first half's MFMAs to be issued, the SIMD's other wave
+                    // covers the latency
+                    cv::BHalf b;
+                    f32x4 acc = keep ? dcur[t] : zero;
+                    cv::load_b_half<0>(lds_base, tl, b);
+                    cv::wait_half(b);
+                    cv::mma_half<0>(w, b, acc);
+                    cv::load_b_half<1>(lds_base, tl, b);
+                    cv::wait_half(b);
+                    cv::mma_half<1>(w, b, acc);
+                    dcur[t] = acc;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- d(a_0) (channels 0..T-1) -> D [C][T][vi] at the start of the region: v.view(N, T, C, V) (model.py:187)
+    // backwards, plane (ch, row) is flat f = ch*C + row = c*T + t of the block output.  The dz image is dead.
+    float *D = region;
+#pragma unroll
+    for (int t = 0; t < kX6Tiles; ++t) {
+        const int p = 16 * t + nq;
+        if (p < npos && kq < T / 4) {
+            const unsigned hw = ptab[p];
+            const int h = (int)(hw >> 8), ww = (int)(hw & 0xffu);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) D[((4 * kq + r) * C + h) * vi + ww] = dcur[t][r];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    txp_bwd_block_tail(a, blk_params, n, vi, region, nullptr, ptab, tot, slope_row, true);
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_bwd_x6_kernel(
+    const TxpBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Vl = a.Vl, wave = threadIdx.x >> 6;
+    const int per_wave = bwd6_region_floats(Vl) + bwd_ptab_floats(Vl);
+    float *region = sm + wave * per_wave;
+    ptab_t *ptab = reinterpret_cast<ptab_t *>(region + bwd6_region_floats(Vl));
+    float *tot = region + bwd6_region_floats(Vl) + ptab_floats(Vl);
+    float *blk_p = sm + WPB * per_wave;
+    stage_block_params(a.lay, a.params, nullptr, blk_p, nullptr, WPB * 64);
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;
+    int begin, end;
+    tier_range(a.tier, a.N, a.V, begin, end);
+    const int M = end - begin;
+    for (int r = 0; r * nw < M; ++r) {
+        const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
+        if (it < 0) continue;
+        const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
+        txp_bwd_scene_x6(a, blk_p, n, region, ptab, tot);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // mixed-V launch: class assignment of a workgroup (see MixGeom)
 // ------------------------------------------------------------------------------------------
 struct MixSlot {
@@ -1061,8 +1305,36 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
     return STG_OK;
 }
 
+bool txp_bwd_x6_fits(const ModelLayout &L, int V) {
+    return L.n_txp > 0 && V <= 16 * kX6Tiles / C && !(L.flags & (STG_OPT_BF16_STORE | STG_OPT_SPLIT_BF16)) &&
+           !diag_env("STG_BWD_F32", 0);
+}
+int64_t txp_bwd_x6_wp_floats(const ModelLayout &L) { return (int64_t)(L.L + 1) * cv::kWpDwords; }
+int launch_txp_bwd_prep(const ModelLayout &L, const float *params, unsigned *wp, hipStream_t st) {
+    hipLaunchKernelGGL(txp_bwd_prep_kernel, dim3((L.L + 1) * cv::kWpVecs), dim3(64), 0, st, L, params, wp);
+    STG_LAUNCH_CHECK("txp_bwd_prep");
+    return STG_OK;
+}
+
 int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {
     TxpBwdArgs a = a0;
+    if (a.wp && txp_bwd_x6_fits(a.lay, a.V)) {
+        const size_t per_wave = (size_t)(bwd6_region_floats(a.Vl) + bwd_ptab_floats(a.Vl)) * sizeof(float);
+        const int wpb = wave_wpb(per_wave);
+        const size_t lds = per_wave * wpb + wave_param_floats(a.lay) * sizeof(float);
+        const dim3 grid(wave_grid(lds, wpb, a.N));
+#define STG_LX(W)                                                                                             \
+    do {                                                                                                      \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_bwd_x6_kernel<W>),            \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+        if (e_ != hipSuccess) return hip_fail(e_, "txp_bwd_x6: hipFuncSetAttribute");                         \
+        hipLaunchKernelGGL((txp_bwd_x6_kernel<W>), grid, dim3(W * 64), lds, st, a);                           \
+    } while (0)
+        if (wpb == 8) STG_LX(8); else if (wpb == 4) STG_LX(4); else if (wpb == 2) STG_LX(2); else STG_LX(1);
+#undef STG_LX
+        STG_LAUNCH_CHECK("txp_bwd_x6");
+        return STG_OK;
+    }
     if (mix_geom(bwd_per_wave_floats, a.V, a.tier.order && a.tier.key_start, &a.mix)) {
         const size_t lds = ((size_t)a.mix.block_floats + wave_param_floats(a.lay)) * sizeof(float);
         const void *fn = a.split_bf16 ? reinterpret_cast<const void *>(&txp_bwd_wave_mixed_kernel<true>)

@@ -264,13 +264,16 @@ def test_fused_loss_backward_equals_loss_kernel_then_backward(dev):
     y2.backward(dy)
     assert torch.allclose(losses.cpu(), l2.cpu(), rtol=2e-6, atol=1e-6)
     assert float(losses[7]) == 0.0
+    gmax = max(float(p.grad.abs().max()) for p in m2.parameters() if p.grad is not None)
     for k, p in m2.named_parameters():
         if p.grad is None:
             assert fused[k] is None, k
             continue
         ref = p.grad.detach().cpu()
-        scale = max(1e-6, float(ref.abs().max()))
-        assert float((fused[k] - ref).abs().max()) <= 2e-6 * scale + 1e-9, k
+        # (biases in front of a train-mode BatchNorm have an exactly-zero true gradient: both sides hold rounding noise
+        # there, compared on the scale of the largest gradient)
+        scale = max(1e-3 * gmax, float(ref.abs().max()))
+        assert float((fused[k] - ref).abs().max()) <= 2e-6 * scale, k
     del state
     # workgroup-per-scene kernels: nothing fused, the caller is told so
     ops.OPTIONS["wg_path"] = True
