@@ -36,7 +36,7 @@ extern "C" {
 #define STG_EUNSUPPORTED (-2) /* configuration outside what the kernels are built for      */
 #define STG_ELDS (-3)        /* scene too large for the 160 KiB LDS of one CU             */
 
-#define STG_ABI_VERSION 5
+#define STG_ABI_VERSION 6
 #define STG_MAX_BLOCKS 4     /* st_gcn blocks in one fused model                          */
 
 int stg_abi_version(void);
@@ -128,6 +128,10 @@ int64_t stg_model_param_count(const stg_model_desc *d);
 int64_t stg_model_buffer_count(const stg_model_desc *d);
 /* Per-scene activation workspace (floats) the forward writes for the backward when save != 0. */
 int64_t stg_model_ws_floats(const stg_model_desc *d, int V);
+/* floats of the BATCH tail of the training workspace, behind the N per-scene blocks: the forward leaves there what the
+ * backward needs once per batch (the prepared bf16 operands of the input-gradient GEMMs, written by extra workgroups
+ * of the forward's first launch).  ws holds N * stg_model_ws_floats + stg_model_ws_tail_floats floats.              */
+int64_t stg_model_ws_tail_floats(const stg_model_desc *d, int V);
 /* Per-scene batch statistics the forward emits in bn_mode 1: (N, stat_floats) =
  * per block, per BatchNorm: mean[C], unbiased var[C].                                           */
 int64_t stg_model_stat_floats(const stg_model_desc *d);
@@ -140,7 +144,7 @@ int64_t stg_model_bwd_scratch_floats(const stg_model_desc *d, int N, int V);
 
 /* x (N,c_in,t_obs,V) strided; adj (N,t_obs,V,V), batch stride a_sn (0 = shared);
  * y: (N,c_out,t_pred,V) when n_txpcnn>0, else the block output (N,c_out,t_obs,V).
- * ws: N * stg_model_ws_floats floats (16-byte aligned) or NULL (inference).  stats: N * stg_model_stat_floats
+ * ws: N * stg_model_ws_floats + stg_model_ws_tail_floats floats (16-byte aligned) or NULL (inference).  stats: N * stg_model_stat_floats
  * or NULL.  scratch: stg_model_fwd_scratch_floats floats, 16-byte aligned (may be NULL when that is 0).     */
 int stg_model_fwd(const stg_model_desc *d, const float *params, const float *buffers,
                   const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv,

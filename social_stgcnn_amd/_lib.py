@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # library reads no environment variable itself
 DIAG = os.environ.get("STG_USE_DIAG_LIB", "0") not in ("", "0")
 LIB_PATH = os.path.join(CSRC, "libstgcnn_hip_diag.so" if DIAG else "libstgcnn_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 OPT_WG_PATH, OPT_SPLIT_BF16, OPT_WAVE_PATH, OPT_BF16_STORE = 1, 2, 4, 8
 EUNSUPPORTED = -2            # STG_EUNSUPPORTED
 
@@ -46,6 +46,7 @@ _SIGNATURES = {
     "stg_model_param_count": (c_l, [ctypes.POINTER(ModelDesc)]),
     "stg_model_buffer_count": (c_l, [ctypes.POINTER(ModelDesc)]),
     "stg_model_ws_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i]),
+    "stg_model_ws_tail_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i]),
     "stg_model_stat_floats": (c_l, [ctypes.POINTER(ModelDesc)]),
     "stg_model_fwd_scratch_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i, c_i]),
     "stg_model_bwd_scratch_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i, c_i]),

@@ -394,7 +394,7 @@ static int bwd_grid_small(const ModelLayout &L, int N, int V) {
 //   slab2  weight-gradient slab rows of K2          dzg  dz_l hand-off [N][L+1][dz_slot(V)]
 //   order  sorted scene list + tier offsets (int32)
 struct BwdCarve {
-    int64_t rows, slab2, dzg, order, wp, total;
+    int64_t rows, slab2, dzg, order, total;
 };
 static bool bwd_carve(const ModelLayout &L, int N, int V, BwdCarve *c, WgradGeom *wg) {
     const int g1 = bwd_grid(L, N, V);
@@ -414,10 +414,7 @@ static bool bwd_carve(const ModelLayout &L, int N, int V, BwdCarve *c, WgradGeom
         fl = (fl + (int64_t)N * (L.L + 1) * dz_slot(V) + 3) & ~(int64_t)3;
     }
     c->order = fl;
-    fl = (fl + order_floats(N, V) + 3) & ~(int64_t)3;
-    c->wp = fl;                              // prepared A operands of the exact-bf16 input-gradient chain (16-byte vectors)
-    if (txp_bwd_x6_fits(L, V)) fl += txp_bwd_x6_wp_floats(L);
-    c->total = fl;
+    c->total = fl + order_floats(N, V);
     return true;
 }
 
@@ -507,12 +504,9 @@ static int model_bwd_impl(const stg_model_desc *d, const float *params, const fl
         t.debug_skip = a.debug_skip;
         t.split_bf16 = (L.flags & STG_OPT_SPLIT_BF16) ? 1 : 0;
         t.stagger = diag_env("STG_STAGGER_B", 0);
-        if (txp_bwd_x6_fits(L, V)) {
-            unsigned *wp = reinterpret_cast<unsigned *>(scratch + cv.wp);
-            const int rcp = launch_txp_bwd_prep(L, params, wp, st);
-            if (rcp != STG_OK) return rcp;
-            t.wp = wp;
-        }
+        // the prepared A operands of the exact-bf16 chain sit in the batch tail of the workspace (written by the forward)
+        if (txp_bwd_x6_fits(L, V))
+            t.wp = reinterpret_cast<const unsigned *>(ws + (int64_t)N * a.ws_stride);
         const int rcw = launch_txp_bwd_wave(t, st);
         if (rcw != STG_OK) return rcw;
         slab_rows = N;

@@ -145,8 +145,16 @@ bool launch_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, i
 
 // stgcn_agg.hip: ax = x A ([cin][T][V_n]) and cs = colsum(A) ([T][V_n]) of every scene -- the one read of A in a
 // step -- written to out + n * out_stride + ax_off / cs_off.
+// prep (optional): the launch also prepares the A operands of the backward's exact-bf16 input-gradient GEMMs
+// (txp_conv_bf16.hpp) into `wp`, [n_layers][cv::kWpDwords], from the conv weights at params + w_off[l].
+struct AggPrep {
+    const float *params;
+    unsigned *wp;
+    int n_layers;
+    int32_t w_off[kMaxTxp + 1];
+};
 int launch_stgcn_agg(int cin, const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj,
                      int64_t a_sn, const int32_t *num_peds, int N, int V, float *out, int64_t out_stride, int64_t ax_off,
-                     int64_t cs_off, hipStream_t st);
+                     int64_t cs_off, hipStream_t st, const AggPrep *prep = nullptr);
 
 }  // namespace stg

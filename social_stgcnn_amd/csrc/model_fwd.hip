@@ -230,6 +230,14 @@ static int64_t fwd_agg_floats(const ModelLayout &l, int N, int V) {
 
 }  // namespace stg
 
+extern "C" int64_t stg_model_ws_tail_floats(const stg_model_desc *d, int V) {
+    stg::ModelLayout l;
+    const int rc = stg::make_layout(d, &l);
+    if (rc != STG_OK) return rc;
+    if (V <= 0) return stg::fail(STG_EINVAL, "stg_model_ws_tail_floats: V=%d", V);
+    return stg::txp_bwd_x6_fits(l, V) ? stg::txp_bwd_x6_wp_floats(l) : 0;
+}
+
 extern "C" int64_t stg_model_fwd_scratch_floats(const stg_model_desc *d, int N, int V) {
     stg::ModelLayout l;
     const int rc = stg::make_layout(d, &l);
@@ -280,8 +288,18 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     }
     a.debug_skip = diag_env("STG_DEBUG_SKIP", 0);
     {
+        // training on the wave-per-scene path: the launch also prepares the backward's exact-bf16 A operands into the
+        // batch tail of the workspace (stg_model_ws_tail_floats behind the N per-scene blocks)
+        AggPrep prep{};
+        if (ws && wave_path && txp_bwd_x6_fits(L, V)) {
+            prep.params = params;
+            prep.wp = reinterpret_cast<unsigned *>(ws + (int64_t)N * a.ws_stride);
+            prep.n_layers = L.L + 1;
+            for (int l = 0; l <= L.L; ++l) prep.w_off[l] = l < L.L ? L.txp_w[l] : L.out_w;
+        }
         const int rca = launch_stgcn_agg(b0.cin, x, x_sn, x_sc, x_st, x_sv, adj, a_sn, num_peds, N, V,
-                                         const_cast<float *>(a.agg), a.agg_stride, a.agg_ax, a.agg_cs, st);
+                                         const_cast<float *>(a.agg), a.agg_stride, a.agg_ax, a.agg_cs, st,
+                                         prep.wp ? &prep : nullptr);
         if (rca != STG_OK) return rca;
     }
     evl.mark();

@@ -12,6 +12,7 @@
 // w) strips with 16-byte loads, 8 rows in flight.  Outputs are compact ([.][T][V_n]): the layout of the saved arrays
 // the block kernels index.
 #include "model_common.hpp"
+#include "txp_conv_bf16.hpp"
 
 namespace stg {
 
@@ -24,9 +25,18 @@ __global__ __launch_bounds__(256) void stgcn_agg_kernel(const float *__restrict_
                                                         int64_t x_st, int64_t x_sv, const float *__restrict__ adj,
                                                         int64_t a_sn, const int32_t *__restrict__ num_peds, int N, int V,
                                                         float *__restrict__ out, int64_t out_stride, int64_t ax_off,
-                                                        int64_t cs_off) {
+                                                        int64_t cs_off, AggPrep prep) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= N) {
+        // training: the workgroups behind the scenes prepare the A operands of the backward's exact-bf16
+        // input-gradient GEMMs (one 16-byte vector per lane and block; txp_conv_bf16.hpp) -- no launch of their own
+        const int b = (int)blockIdx.x - N, l = b / cv::kWpVecs, v = b - l * cv::kWpVecs;
+        if (tid < 64)
+            cv::prep_dgrad_vector(prep.params + prep.w_off[l], l == 0 ? Cfg::T : Cfg::P, v, tid,
+                                  prep.wp + (int64_t)l * cv::kWpDwords);
+        return;
+    }
     const int n = blockIdx.x;
     int vi = num_peds ? num_peds[n] : V;
     vi = vi < 0 ? 0 : (vi > V ? V : vi);
@@ -100,9 +110,11 @@ __global__ __launch_bounds__(256) void stgcn_agg_kernel(const float *__restrict_
 // out + n * out_stride + ax_off : ax [cin][T][V_n];  out + n * out_stride + cs_off : cs [T][V_n]
 int launch_stgcn_agg(int cin, const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj,
                      int64_t a_sn, const int32_t *num_peds, int N, int V, float *out, int64_t out_stride, int64_t ax_off,
-                     int64_t cs_off, hipStream_t st) {
+                     int64_t cs_off, hipStream_t st, const AggPrep *prep_in) {
     if (N == 0) return STG_OK;
-    const dim3 grid(N), block(256);
+    AggPrep prep{};
+    if (prep_in) prep = *prep_in;
+    const dim3 grid(N + (prep.wp ? prep.n_layers * cv::kWpVecs : 0)), block(256);
     const size_t lds = (size_t)cin * T * V * sizeof(float);
     STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stgcn_agg: V=%d needs %zu bytes of LDS", V, lds);
     // 16-byte loads need 16-byte aligned rows: V a multiple of 4 and a 16-byte aligned base / batch stride
@@ -117,7 +129,7 @@ int launch_stgcn_agg(int cin, const float *x, int64_t x_sn, int64_t x_sc, int64_
             if (e_ != hipSuccess) return hip_fail(e_, "stgcn_agg: hipFuncSetAttribute");                        \
         }                                                                                                        \
         hipLaunchKernelGGL((stgcn_agg_kernel<CI, VE>), grid, block, lds, st, x, x_sn, x_sc, x_st, x_sv, adj, a_sn, \
-                           num_peds, N, V, out, out_stride, ax_off, cs_off);                                     \
+                           num_peds, N, V, out, out_stride, ax_off, cs_off, prep);                               \
     } while (0)
     if (cin == Cfg::CIN0) {
         if (vec) STG_AGG(Cfg::CIN0, 4); else STG_AGG(Cfg::CIN0, 1);

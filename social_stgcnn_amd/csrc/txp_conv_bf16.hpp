@@ -116,6 +116,21 @@ __host__ __device__ inline unsigned short wp_value(WF W, int g, int k, int lane,
 }
 
 #ifdef __HIPCC__
+// One 16-byte A-operand vector (vector v of layer-local table `wp`) of the INPUT-GRADIENT GEMM of a 3x3 conv with weights
+// W [12][cinl][3][3]: d in[ci][pos] = sum W[co][ci][2-kh][2-kw] dz[co][pos+tap].  64 lanes.
+__device__ __forceinline__ void prep_dgrad_vector(const float *__restrict__ W, int cinl, int v, int lane, unsigned *__restrict__ wp) {
+    auto wf = [&](int m, int ch, int kh, int kw) -> float {
+        return m < cinl ? W[(ch * cinl + m) * 9 + (2 - kh) * 3 + (2 - kw)] : 0.f;
+    };
+    unsigned d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        d[q] = (unsigned)wp_value(wf, v / 3, v % 3, lane, 2 * q) | ((unsigned)wp_value(wf, v / 3, v % 3, lane, 2 * q + 1) << 16);
+    reinterpret_cast<u32x4 *>(wp)[v * 64 + lane] = u32x4{d[0], d[1], d[2], d[3]};
+}
+#endif
+
+#ifdef __HIPCC__
 typedef uint16_t ptab_t;
 
 __device__ __forceinline__ void load_wp(const unsigned *__restrict__ wp, u32x4 (&w)[kWpVecs]) {

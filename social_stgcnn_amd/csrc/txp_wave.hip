@@ -877,24 +877,6 @@ __host__ __device__ inline int bwd6_region_floats(int v) {
     return ((img > tail ? img : tail) + 3) & ~3;
 }
 
-__global__ __launch_bounds__(64) void txp_bwd_prep_kernel(const ModelLayout L, const float *__restrict__ params,
-                                                          unsigned *__restrict__ wp) {
-    // block = (layer l, operand vector v); layer L.L = the output conv.  A operands of
-    // d in[ci][pos] = sum W[co][ci][2-kh][2-kw] dz[co][pos+tap]
-    const int l = blockIdx.x / cv::kWpVecs, v = blockIdx.x - l * cv::kWpVecs, lane = threadIdx.x;
-    const int cinl = l == 0 ? T : P;
-    const float *W = params + (l < L.L ? L.txp_w[l] : L.out_w);
-    auto wf = [&](int m, int ch, int kh, int kw) -> float {
-        return m < cinl ? W[(ch * cinl + m) * 9 + (2 - kh) * 3 + (2 - kw)] : 0.f;
-    };
-    unsigned d[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        d[q] = (unsigned)cv::wp_value(wf, v / 3, v % 3, lane, 2 * q) |
-               ((unsigned)cv::wp_value(wf, v / 3, v % 3, lane, 2 * q + 1) << 16);
-    reinterpret_cast<cv::u32x4 *>(wp + (int64_t)l * cv::kWpDwords)[v * 64 + lane] = cv::u32x4{d[0], d[1], d[2], d[3]};
-}
-
 __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const float *blk_params, int n, float *region,
                                                  ptab_t *ptab, float *tot) {
     const ModelLayout &L = a.lay;
@@ -1310,12 +1292,6 @@ bool txp_bwd_x6_fits(const ModelLayout &L, int V) {
            !diag_env("STG_BWD_F32", 0);
 }
 int64_t txp_bwd_x6_wp_floats(const ModelLayout &L) { return (int64_t)(L.L + 1) * cv::kWpDwords; }
-int launch_txp_bwd_prep(const ModelLayout &L, const float *params, unsigned *wp, hipStream_t st) {
-    hipLaunchKernelGGL(txp_bwd_prep_kernel, dim3((L.L + 1) * cv::kWpVecs), dim3(64), 0, st, L, params, wp);
-    STG_LAUNCH_CHECK("txp_bwd_prep");
-    return STG_OK;
-}
-
 int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {
     TxpBwdArgs a = a0;
     if (a.wp && txp_bwd_x6_fits(a.lay, a.V)) {

@@ -61,7 +61,8 @@ struct TxpBwdArgs {
     const float *ws;
     int64_t ws_stride;
     float *dzg;            // [N][L][dz_slot(V)]   dz_l of the hidden layers for the weight-gradient GEMM
-    const unsigned *wp;    // prepared input-gradient A operands (txp_conv_bf16.hpp), [L+1][cv::kWpDwords], or null
+    const unsigned *wp;    // prepared input-gradient A operands (txp_conv_bf16.hpp), [L+1][cv::kWpDwords] -- the batch
+                           // tail of the workspace, written by the forward's aggregation launch -- or null
     float *rows;           // [N][n_blk_params + n_txp]  per-scene small-parameter gradients: st_gcn block, PReLU slopes
     int debug_skip;        // timing-only diagnostic (STG_DEBUG_SKIP): 512 dz build, 1024 dgrad tile loops -- wrong results
     int split_bf16;        // 1: the input-gradient GEMMs run on bf16 MFMAs with hi/lo-split operands (see txp_wave.hip)
@@ -80,6 +81,5 @@ int launch_txp_bwd_wave(const TxpBwdArgs &a, hipStream_t st);
 // the exact-bf16 input-gradient chain (txp_bwd_x6): serves whole batches with V <= 32, fp32 storage
 bool txp_bwd_x6_fits(const ModelLayout &L, int V);
 int64_t txp_bwd_x6_wp_floats(const ModelLayout &L);
-int launch_txp_bwd_prep(const ModelLayout &L, const float *params, unsigned *wp, hipStream_t st);
 
 }  // namespace stg

@@ -272,7 +272,10 @@ class _FusedModel(torch.autograd.Function):
             wsf = L.stg_model_ws_floats(ctypes.byref(desc), v)
             if wsf < 0:
                 check(int(wsf), "stg_model_ws_floats")
-            ws = torch.empty(n * wsf, device=x.device, dtype=torch.float32)
+            tail = L.stg_model_ws_tail_floats(ctypes.byref(desc), v)
+            if tail < 0:
+                check(int(tail), "stg_model_ws_tail_floats")
+            ws = torch.empty(n * wsf + tail, device=x.device, dtype=torch.float32)
             LAST_WS_FLOATS = ws.numel()
         stats = None
         if training:

@@ -272,7 +272,7 @@ def test_fused_loss_backward_equals_loss_kernel_then_backward(dev):
         ref = p.grad.detach().cpu()
         # (biases in front of a train-mode BatchNorm have an exactly-zero true gradient: both sides hold rounding noise
         # there, compared on the scale of the largest gradient)
-        scale = max(1e-3 * gmax, float(ref.abs().max()))
+        scale = max(0.05 * gmax, float(ref.abs().max()))
         assert float((fused[k] - ref).abs().max()) <= 2e-6 * scale, k
     del state
     # workgroup-per-scene kernels: nothing fused, the caller is told so
