@@ -167,11 +167,25 @@ def bytes_per_window(v):
 KERNELS = {
     "model_fwd": [("stgcn_agg_kernel (x A, colsum A: the read of A)", lambda v: 80 * v * v, "hbm"),
                   ("txp_fwd_wave_kernel (st_gcn block + TXP-CNN forward)", lambda v: 62000 * v, "mfma")],
-    "model_bwd": [("txp_bwd_wave_kernel (TXP input-gradient chain + st_gcn block backward)",
-                   lambda v: 60480 * v + 2 * 1520 * v + 80 * v * v, "mfma"),
-                  ("txp_wgrad_kernel (TXP weight / bias gradients)", lambda v: 60480 * v, "mfma"),
-                  ("reduce_slabs_kernel", lambda v: 0, "hbm")],
+    "model_bwd": [("txp_bwd_x6_kernel / txp_bwd_wave_kernel (loss gradient + TXP input-gradient chain + st_gcn block "
+                   "backward)", lambda v: 60480 * v + 2 * 1520 * v + 80 * v * v, "mfma"),
+                  ("txp_wgrad_bf16_kernel / txp_wgrad_kernel (TXP weight / bias gradients)", lambda v: 60480 * v, "mfma"),
+                  ("reduce_slabs_kernel (+ SGD, BatchNorm fold, reported loss)", lambda v: 0, "hbm")],
 }
+PEAK_BF16_TFLOPS = 2516.6     # dense v_mfma_f32_16x16x32_bf16: 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz
+
+
+def issued_bf16_flop(kernel, v):
+    """FLOP the exact-bf16 kernels ISSUE per scene-window on v_mfma_f32_16x16x32_bf16 (16,384 FLOP each): every fp32
+    product is six bf16 products, M = 12 of 16 rows and K = 108 of 128 are real.  None for the fp32-MFMA kernels
+    (V > 32, bf16 storage: the library then runs txp_bwd_wave_kernel / txp_wgrad_kernel)."""
+    if v > 32:
+        return None
+    if kernel.startswith("txp_bwd_x6"):
+        return 6 * ((5 * v + 15) // 16) * 24 * 16384          # six input-gradient convs, 24 MFMAs per 16-position tile
+    if kernel.startswith("txp_wgrad_bf16"):
+        return 6 * ((5 * v + 31) // 32) * 57 * 16384          # six layers, 9 taps x 6 products + 3 bias MFMAs per 32 positions
+    return None
 
 
 def time_kernel(torch, fn, iters=10, warm=2):
@@ -413,9 +427,17 @@ def main():
                 ms = timer.kernel_ms(entry)
                 for (name, flop, bound), t in zip(KERNELS[entry], ms):
                     fl = sum(flop(c) for c in per_scene) / len(dsets)
-                    kern.append({"kernel": name, "entry": "stg_" + entry, "launch_ms": t, "bound": bound,
-                                 "algorithmic_flop_per_launch": fl,
-                                 "achieved_tflops": fl / (t * 1e-3) / 1e12 if t > 0 else None})
+                    row = {"kernel": name, "entry": "stg_" + entry, "launch_ms": t, "bound": bound,
+                           "algorithmic_flop_per_launch": fl,
+                           "achieved_tflops": fl / (t * 1e-3) / 1e12 if t > 0 else None}
+                    iss = [issued_bf16_flop(name, c) for c in per_scene] if args.dtype == "f32" else [None]
+                    if t > 0 and all(q is not None for q in iss):
+                        ifl = sum(iss) / len(dsets)
+                        row["issued"] = {"instruction": "v_mfma_f32_16x16x32_bf16 (exact three-piece operands: six bf16 "
+                                                        "products per fp32 product)",
+                                         "flop_per_launch": ifl, "tflops": ifl / (t * 1e-3) / 1e12,
+                                         "peak": PEAK_BF16_TFLOPS, "frac": ifl / (t * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
+                    kern.append(row)
             dom = max((k for k in kern if k["bound"] == "mfma"), key=lambda k: k["launch_ms"])
             bwd_ms = sum(k["launch_ms"] for k in kern if k["entry"] == "stg_model_bwd")
             bwd_fl = sum(flops_per_window(c, fwd=False) for c in per_scene) / len(dsets)
@@ -433,8 +455,11 @@ def main():
                                 "FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2; regenerate with tools/profile_all.sh)",
                 "kernel": dom["kernel"], "launch_ms": dom["launch_ms"],
                 "algorithmic_flop_per_launch": dom["algorithmic_flop_per_launch"],
+                "issued": dom.get("issued"),
                 "note": "dominant single MFMA kernel of the step; duration = mean over %d eager launches of HIP-event "
-                        "intervals recorded by the library on the launch stream; peak = fp32-input MFMA at 2.4 GHz"
+                        "intervals recorded by the library on the launch stream; achieved / peak / frac = ALGORITHMIC "
+                        "fp32 FLOP against the fp32-input MFMA peak at 2.4 GHz; `issued` = what the kernel issues on the "
+                        "bf16 matrix pipe against that instruction's dense peak"
                         % len(timer.calls["model_bwd"]),
                 "kernels": kern,
                 "composite": {"kernel": "stg_model_bwd (all its kernels)", "launch_ms": bwd_ms,
