@@ -149,7 +149,8 @@ bool launch_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, i
 // (txp_conv_bf16.hpp) into `wp`, [n_layers][cv::kWpDwords], from the conv weights at params + w_off[l].
 struct AggPrep {
     const float *params;
-    unsigned *wp;
+    unsigned *wp;          // input-gradient operands (training: the workspace's batch tail) or null
+    unsigned *wp_fwd;      // forward operands (the forward's scratch) or null
     int n_layers;
     int32_t w_off[kMaxTxp + 1];
 };

@@ -228,6 +228,11 @@ static int64_t fwd_agg_floats(const ModelLayout &l, int N, int V) {
     return (((int64_t)N * (l.blk[0].cin + 1) * Cfg::T * V + 3) & ~(int64_t)3) + 4;
 }
 
+// ... | prepared forward operands of the exact-bf16 convs (16-byte vectors)]
+static int64_t fwd_wp_off(const ModelLayout &l, int N, int V, bool stamps) {
+    return (fwd_agg_floats(l, N, V) + order_floats(N, V) + (stamps ? (int64_t)N * 32 : 0) + 3) & ~(int64_t)3;
+}
+
 }  // namespace stg
 
 extern "C" int64_t stg_model_ws_tail_floats(const stg_model_desc *d, int V) {
@@ -244,7 +249,7 @@ extern "C" int64_t stg_model_fwd_scratch_floats(const stg_model_desc *d, int N, 
     if (rc != STG_OK) return rc;
     if (N < 0 || V <= 0) return stg::fail(STG_EINVAL, "stg_model_fwd_scratch_floats: N=%d V=%d", N, V);
     const bool stamps = stg::diag_env("STG_STAMPS", 0) != 0;
-    return stg::fwd_agg_floats(l, N, V) + stg::order_floats(N, V) + (stamps ? (int64_t)N * 32 : 0);
+    return stg::fwd_wp_off(l, N, V, stamps) + (stg::txp_fwd_x6_fits(l, V) ? stg::txp_bwd_x6_wp_floats(l) : 0);
 }
 
 extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const float *buffers, const float *x,
@@ -291,15 +296,16 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         // training on the wave-per-scene path: the launch also prepares the backward's exact-bf16 A operands into the
         // batch tail of the workspace (stg_model_ws_tail_floats behind the N per-scene blocks)
         AggPrep prep{};
-        if (ws && wave_path && txp_bwd_x6_fits(L, V)) {
-            prep.params = params;
-            prep.wp = reinterpret_cast<unsigned *>(ws + (int64_t)N * a.ws_stride);
-            prep.n_layers = L.L + 1;
-            for (int l = 0; l <= L.L; ++l) prep.w_off[l] = l < L.L ? L.txp_w[l] : L.out_w;
-        }
+        prep.params = params;
+        prep.n_layers = L.L + 1;
+        for (int l = 0; l <= L.L; ++l) prep.w_off[l] = l < L.L ? L.txp_w[l] : L.out_w;
+        if (ws && wave_path && txp_bwd_x6_fits(L, V)) prep.wp = reinterpret_cast<unsigned *>(ws + (int64_t)N * a.ws_stride);
+        // ... and the forward's own (this launch's successor reads them from the scratch buffer)
+        if (wave_path && txp_fwd_x6_fits(L, V))
+            prep.wp_fwd = reinterpret_cast<unsigned *>(scratch + fwd_wp_off(L, N, V, diag_env("STG_STAMPS", 0) != 0));
         const int rca = launch_stgcn_agg(b0.cin, x, x_sn, x_sc, x_st, x_sv, adj, a_sn, num_peds, N, V,
                                          const_cast<float *>(a.agg), a.agg_stride, a.agg_ax, a.agg_cs, st,
-                                         prep.wp ? &prep : nullptr);
+                                         (prep.wp || prep.wp_fwd) ? &prep : nullptr);
         if (rca != STG_OK) return rca;
     }
     evl.mark();
@@ -314,6 +320,8 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         t.adj = adj; t.a_sn = a_sn;
         t.agg = a.agg; t.agg_stride = a.agg_stride; t.agg_ax = a.agg_ax; t.agg_cs = a.agg_cs;
         t.y = y; t.ws = ws; t.ws_stride = a.ws_stride; t.stats = stats;
+        if (txp_fwd_x6_fits(L, V))
+            t.wpf = reinterpret_cast<const unsigned *>(scratch + fwd_wp_off(L, N, V, diag_env("STG_STAMPS", 0) != 0));
         t.stamps = diag_env("STG_STAMPS", 0) ? reinterpret_cast<unsigned long long *>(scratch + fwd_agg_floats(L, N, V) + order_floats(N, V)) : nullptr;
         const int serp = diag_env("STG_WALK", 1);
         // one launch for the whole (sorted) batch: V-tiers in separate launches were measured slower -- the few

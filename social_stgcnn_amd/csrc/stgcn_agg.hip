@@ -31,10 +31,20 @@ __global__ __launch_bounds__(256) void stgcn_agg_kernel(const float *__restrict_
     if ((int)blockIdx.x >= N) {
         // training: the workgroups behind the scenes prepare the A operands of the backward's exact-bf16
         // input-gradient GEMMs (one 16-byte vector per lane and block; txp_conv_bf16.hpp) -- no launch of their own
-        const int b = (int)blockIdx.x - N, l = b / cv::kWpVecs, v = b - l * cv::kWpVecs;
-        if (tid < 64)
-            cv::prep_dgrad_vector(prep.params + prep.w_off[l], l == 0 ? Cfg::T : Cfg::P, v, tid,
-                                  prep.wp + (int64_t)l * cv::kWpDwords);
+        int b = (int)blockIdx.x - N;
+        const bool fwd = b >= prep.n_layers * cv::kWpVecs;
+        if (fwd) b -= prep.n_layers * cv::kWpVecs;
+        const int l = b / cv::kWpVecs, v = b - l * cv::kWpVecs;
+        if (tid < 64) {
+            if (fwd) {
+                if (prep.wp_fwd)
+                    cv::prep_fwd_vector(prep.params + prep.w_off[l], l == 0 ? Cfg::T : Cfg::P, v, tid,
+                                        prep.wp_fwd + (int64_t)l * cv::kWpDwords);
+            } else if (prep.wp) {
+                cv::prep_dgrad_vector(prep.params + prep.w_off[l], l == 0 ? Cfg::T : Cfg::P, v, tid,
+                                      prep.wp + (int64_t)l * cv::kWpDwords);
+            }
+        }
         return;
     }
     const int n = blockIdx.x;
@@ -114,7 +124,7 @@ int launch_stgcn_agg(int cin, const float *x, int64_t x_sn, int64_t x_sc, int64_
     if (N == 0) return STG_OK;
     AggPrep prep{};
     if (prep_in) prep = *prep_in;
-    const dim3 grid(N + (prep.wp ? prep.n_layers * cv::kWpVecs : 0)), block(256);
+    const dim3 grid(N + ((prep.wp || prep.wp_fwd) ? 2 * prep.n_layers * cv::kWpVecs : 0)), block(256);
     const size_t lds = (size_t)cin * T * V * sizeof(float);
     STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stgcn_agg: V=%d needs %zu bytes of LDS", V, lds);
     // 16-byte loads need 16-byte aligned rows: V a multiple of 4 and a 16-byte aligned base / batch stride

@@ -461,7 +461,9 @@ template <typename Args>
 __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float *P_, const float *B_, const BlockLayout &b,
                                                      int n, int vi, float *wsn, float *statn, const float *pre_ax,
                                                      const float *pre_cs, float *plane, int plane_sc, float *plane_base,
-                                                     int plane_zero_f4, ptab_t *qtab) {
+                                                     int plane_zero_f4, ptab_t *qtab, float *regs_out = nullptr) {
+    // regs_out (a register array of C*T floats in the caller): the outputs of pedestrian w, flat index f = c*T+t, are
+    // handed back instead of written to `plane` (the exact-bf16 forward splits and stores them itself)
     constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, CIN = Cfg::CIN0;
     [[maybe_unused]] constexpr int WAVES = 0;          // (diagnostic stamps)
     const int w = threadIdx.x & 63, V = a.V;
@@ -697,7 +699,8 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
             // v.view(N, T, C, V) (model.py:187): flat plane index f = c*T+t -> (f / C, f % C), static here
             constexpr int dummy = 0; (void)dummy;
             const int f = c * T + t, ch = f / C, row = f - ch * C;
-            if (act) pw[ch * plane_sc + (row + 1) * SW] = s;
+            if (regs_out) regs_out[f] = act ? s : 0.f;
+            else if (act) pw[ch * plane_sc + (row + 1) * SW] = s;
         }
     }
     __builtin_amdgcn_wave_barrier();

@@ -131,6 +131,20 @@ __device__ __forceinline__ void prep_dgrad_vector(const float *__restrict__ W, i
 #endif
 
 #ifdef __HIPCC__
+// the same for the FORWARD conv: out[co][pos] = sum W[co][ci][kh][kw] in[ci][pos+tap]
+__device__ __forceinline__ void prep_fwd_vector(const float *__restrict__ W, int cinl, int v, int lane, unsigned *__restrict__ wp) {
+    auto wf = [&](int m, int ch, int kh, int kw) -> float {
+        return (m < kCh && ch < cinl) ? W[(m * cinl + ch) * 9 + kh * 3 + kw] : 0.f;
+    };
+    unsigned d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        d[q] = (unsigned)wp_value(wf, v / 3, v % 3, lane, 2 * q) | ((unsigned)wp_value(wf, v / 3, v % 3, lane, 2 * q + 1) << 16);
+    reinterpret_cast<u32x4 *>(wp)[v * 64 + lane] = u32x4{d[0], d[1], d[2], d[3]};
+}
+#endif
+
+#ifdef __HIPCC__
 typedef uint16_t ptab_t;
 
 __device__ __forceinline__ void load_wp(const unsigned *__restrict__ wp, u32x4 (&w)[kWpVecs]) {

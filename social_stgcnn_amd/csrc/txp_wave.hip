@@ -435,6 +435,153 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
 }
 
 // ------------------------------------------------------------------------------------------
+// forward, exact-bf16 variant (x6): the six convs on v_mfma_f32_16x16x32_bf16 with three-piece operands
+// ------------------------------------------------------------------------------------------
+// txp_conv_bf16.hpp.  a_l lives in LDS as three position-major bf16 piece images (7 row slots: no in-place ring is
+// needed, because the layer's outputs stay in REGISTERS until every tile has read its inputs); the same registers are
+// the residual input of the next layer -- a lane owns the same (position, channel quad) of every tile in every layer
+// (<= 10 tiles for V_n <= 32).  The st_gcn block (column mode) hands its outputs over in registers as well.
+constexpr int kF6Tiles = 10, kF6Slots = 7;
+__host__ __device__ inline int fwd6_region_floats(int v) { return (cv::image_bytes(v, kF6Slots) / 4 + 3) & ~3; }
+
+__device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const float *__restrict__ params,
+                                                 const float *blk_params, const float *blk_buffers, int n, float *region,
+                                                 ptab_t *ptab) {
+    const ModelLayout &L = a.lay;
+    const int V = a.V, lane = threadIdx.x & 63, nq = lane & 15, kq = lane >> 4;
+    int vi = a.num_peds ? a.num_peds[n] : V;
+    vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
+    float *yn = a.y + (int64_t)n * (C * P) * V;
+    if (vi < V)                                        // padded pedestrian slots of the output are zeros
+        for (int e = lane; e < C * P * (V - vi); e += 64) {
+            const int r = e / (V - vi), w = vi + (e - r * (V - vi));
+            yn[(int64_t)r * V + w] = 0.f;
+        }
+    if (vi == 0) return;
+    const int npos = C * vi, ntiles = (npos + 15) >> 4;
+    const float *Pm = params;
+    float *wsn = a.ws ? a.ws + n * a.ws_stride : nullptr;
+    float *statn = a.stats ? a.stats + (int64_t)n * L.stat_floats : nullptr;
+    unsigned char *img = reinterpret_cast<unsigned char *>(region);
+    const cv::LaneGeom lg = cv::lane_geom(vi, kF6Slots);
+    const int SWs = vi + 2;                            // row stride (positions) of the saved planes
+
+    // ---- st_gcn block (model.py:145-155), column mode: lane = pedestrian; zeroes the image, builds the position table
+    {
+        float sv[C * T];
+        const float *agn = a.agg + n * a.agg_stride;
+        stgcn_block_fwd_cols(a, blk_params, blk_buffers, L.blk[0], n, vi, wsn, statn, agn + a.agg_ax, agn + a.agg_cs, nullptr,
+                             0, region, (3 * lg.PL) >> 4, ptab, sv);
+        // v.view(N, T, C, V) (model.py:187): flat f = c*T+t of the block output is plane channel f / C, row f % C.  Per
+        // row the lane's eight channels are two record quads; the third quad (channels 8..11) stays zero.
+        float *d2 = wsn ? wsn + ws_plane_off(L, V, 0) : nullptr;
+        if (lane < vi) {
+#pragma unroll
+            for (int row = 0; row < C; ++row) {
+#pragma unroll
+                for (int q = 0; q < T / 4; ++q) {
+                    const f32x4 v4 = {sv[(4 * q + 0) * C + row], sv[(4 * q + 1) * C + row], sv[(4 * q + 2) * C + row],
+                                      sv[(4 * q + 3) * C + row]};
+                    cv::put4(img, (unsigned)(cv::pos_off(vi, 1 + row, lane) + 8 * q), lg.PL, v4);
+                    if (d2) reinterpret_cast<f32x4 *>(d2)[(row * SWs + lane + 1) * 3 + q] = v4;
+                }
+                if (d2) reinterpret_cast<f32x4 *>(d2)[(row * SWs + lane + 1) * 3 + 2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (wsn && lane < 2 * C * 3) {
+            // zero border columns of the saved planes a_0 .. a_L (the weight-gradient GEMM reads them)
+            const int b = lane / 3, q = lane - b * 3, pos = (b >> 1) * SWs + ((b & 1) ? SWs - 1 : 0);
+            for (int l = 0; l <= L.L; ++l)
+                reinterpret_cast<f32x4 *>(wsn + ws_plane_off(L, V, l))[pos * 3 + q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- TXP-CNN (model.py:187-195) -------------------------------------------------------------------
+    const unsigned lds_base = (unsigned)(uintptr_t)img;
+    f32x4 av[kF6Tiles];
+#pragma unroll
+    for (int t = 0; t < kF6Tiles; ++t) av[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l <= L.L; ++l) {
+        const bool is_out = l == L.L;
+        cv::u32x4 w[cv::kWpVecs];
+        cv::load_wp(a.wpf + (int64_t)l * cv::kWpDwords, w);
+        const float *bias = Pm + (is_out ? L.out_b : L.txp_b[l]);
+        f32x4 binit;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) binit[r] = kq < 3 ? bias[4 * kq + r] : 0.f;
+        const float alpha = is_out ? 0.f : Pm[L.prelus + l];
+        float *zs = (wsn && !is_out) ? wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V : nullptr;
+        float *ps = (wsn && !is_out) ? wsn + ws_plane_off(L, V, l + 1) : nullptr;
+#pragma unroll
+        for (int t = 0; t < kF6Tiles; ++t) {
+            if (t < ntiles) {
+                const cv::Tile tl = cv::tile_of<1>(t, ptab, npos, lg, vi);
+                cv::BHalf b;
+                f32x4 z = binit;
+                cv::load_b_half<0>(lds_base, tl, b);
+                cv::wait_half(b);
+                cv::mma_half<0>(w, b, z);
+                cv::load_b_half<1>(lds_base, tl, b);
+                cv::wait_half(b);
+                cv::mma_half<1>(w, b, z);
+                if (tl.ok && kq < 3) {
+                    if (is_out) {
+                        // v.view(N, C, P, V) (model.py:195): the (P, C, V) conv output IS the (C, P, V) tensor
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) yn[(int64_t)((4 * kq + r) * C + tl.h) * V + tl.w] = z[r];
+                    } else {
+                        f32x4 v4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v4[r] = (z[r] > 0.f ? z[r] : alpha * z[r]) + (l > 0 ? av[t][r] : 0.f);
+                        av[t] = v4;
+                        if (zs) {
+                            reinterpret_cast<f32x4 *>(zs)[tl.pos * 3 + kq] = z;
+                            reinterpret_cast<f32x4 *>(ps)[(tl.h * SWs + tl.w + 1) * 3 + kq] = v4;
+                        }
+                    }
+                }
+            }
+        }
+        if (is_out) break;
+        // every tile has read a_l: a_{l+1} replaces it in the image
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < kF6Tiles; ++t) {
+            const int p = 16 * t + nq;
+            if (p < npos && kq < 3) {
+                const unsigned hw = ptab[p];
+                cv::put4(img, (unsigned)(cv::pos_off(vi, 1 + (int)(hw >> 8), (int)(hw & 0xffu)) + 8 * kq), lg.PL, av[t]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_fwd_x6_kernel(
+    const TxpFwdArgs a, const float *__restrict__ params, const float *__restrict__ buffers) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Vl = a.Vl, wave = threadIdx.x >> 6;
+    const int per_wave = fwd6_region_floats(Vl) + ptab_floats(Vl);
+    float *region = sm + wave * per_wave;
+    ptab_t *ptab = reinterpret_cast<ptab_t *>(region + fwd6_region_floats(Vl));
+    float *blk_p = sm + WPB * per_wave, *blk_b = blk_p + ((a.lay.n_blk_params + 3) & ~3);
+    stage_block_params(a.lay, params, buffers, blk_p, blk_b, WPB * 64);
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;
+    int begin, end;
+    tier_range(a.tier, a.N, a.V, begin, end);
+    const int M = end - begin;
+    for (int r = 0; r * nw < M; ++r) {
+        const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
+        if (it < 0) continue;
+        const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
+        txp_fwd_scene_x6(a, params, blk_p, blk_b, n, region, ptab);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward: input-gradient chain
 // ------------------------------------------------------------------------------------------
 template <int CINL>
@@ -1259,8 +1406,30 @@ static int mix_grid(size_t lds_bytes, int N) {
     return g < 4 ? 4 : g;
 }
 
+bool txp_fwd_x6_fits(const ModelLayout &L, int V) {
+    return L.n_txp > 0 && V <= 16 * kF6Tiles / C && !(L.flags & STG_OPT_BF16_STORE) && L.n_blocks == 1 &&
+           L.blk[0].cin == Cfg::CIN0 && !diag_env("STG_FWD_F32", 0);
+}
+
 int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
     TxpFwdArgs a = a0;
+    if (a.wpf && txp_fwd_x6_fits(a.lay, a.V)) {
+        const size_t per_wave = (size_t)(fwd6_region_floats(a.Vl) + ptab_floats(a.Vl)) * sizeof(float);
+        const int wpb = wave_wpb(per_wave);
+        const size_t lds = per_wave * wpb + wave_param_floats(a.lay) * sizeof(float);
+        const dim3 grid(wave_grid(lds, wpb, a.N));
+#define STG_LX(W)                                                                                             \
+    do {                                                                                                      \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_fwd_x6_kernel<W>),            \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+        if (e_ != hipSuccess) return hip_fail(e_, "txp_fwd_x6: hipFuncSetAttribute");                         \
+        hipLaunchKernelGGL(txp_fwd_x6_kernel<W>, grid, dim3(W * 64), lds, st, a, a.params, a.buffers);        \
+    } while (0)
+        if (wpb == 8) STG_LX(8); else if (wpb == 4) STG_LX(4); else if (wpb == 2) STG_LX(2); else STG_LX(1);
+#undef STG_LX
+        STG_LAUNCH_CHECK("txp_fwd_x6");
+        return STG_OK;
+    }
     if (mix_geom(fwd_per_wave_floats, a.V, a.tier.order && a.tier.key_start, &a.mix)) {
         const size_t lds = ((size_t)a.mix.block_floats + wave_param_floats(a.lay)) * sizeof(float);
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_fwd_wave_mixed_kernel),

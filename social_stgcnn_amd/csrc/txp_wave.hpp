@@ -31,6 +31,7 @@ struct TxpFwdArgs {
     const float *agg;      // per scene [agg_stride]: ax at agg_ax ([c_in][T][V_n]), cs at agg_cs ([T][V_n])
     int64_t agg_stride, agg_ax, agg_cs;
     float *y;              // (N, C, P, V)
+    const unsigned *wpf;   // prepared forward A operands (txp_conv_bf16.hpp), [L+1][cv::kWpDwords], or null
     float *ws;             // per-scene workspace or null (inference)
     int64_t ws_stride;
     float *stats;          // (N, stat_floats) per-scene BatchNorm statistics (bn_mode 1) or null
@@ -80,6 +81,7 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a, hipStream_t st);
 int launch_txp_bwd_wave(const TxpBwdArgs &a, hipStream_t st);
 // the exact-bf16 input-gradient chain (txp_bwd_x6): serves whole batches with V <= 32, fp32 storage
 bool txp_bwd_x6_fits(const ModelLayout &L, int V);
+bool txp_fwd_x6_fits(const ModelLayout &L, int V);
 int64_t txp_bwd_x6_wp_floats(const ModelLayout &L);
 
 }  // namespace stg
