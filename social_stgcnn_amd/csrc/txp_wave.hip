@@ -1066,20 +1066,15 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
         } else if (l == L.L) {
             // dz of the output conv is dV_pred: row rc = f * P + p of the (C*P) x V array is channel rc / C, plane row
             // rc % C.  Lanes are laid over (row or prediction step, pedestrian) with the row length rounded up to a power
-            // of two; every value is split and dropped into its record as three 2-byte stores.
+            // of two.
             const int vp = vi <= 1 ? 1 : (vi <= 2 ? 2 : (vi <= 4 ? 4 : (vi <= 8 ? 8 : (vi <= 16 ? 16 : 32))));
             const int sh = __builtin_ctz(vp), rpi = 64 >> sh;
             const int sub = lane >> sh, w = lane & (vp - 1);
             const bool okw = w < vi;
-            auto put1 = [&](int rc, float g) {
-                const int ch = rc / C, h = rc - ch * C;
-                float ph, pm, pl;
-                cv::split3(g, ph, pm, pl);
-                unsigned char *q = img + cv::pos_off(vi, 1 + h, w) + 2 * ch;
-                *reinterpret_cast<unsigned short *>(q) = (unsigned short)cv::hi16(ph);
-                *reinterpret_cast<unsigned short *>(q + lg.PL) = (unsigned short)cv::hi16(pm);
-                *reinterpret_cast<unsigned short *>(q + 2 * lg.PL) = (unsigned short)cv::hi16(pl);
-            };
+            // the values pass through an fp32 staging array S [C*P rows][vi] laid over the (still empty) m / l piece
+            // images: coalesced along the pedestrians here, read back as record quads below
+            float *S = reinterpret_cast<float *>(img + lg.PL);
+            auto put1 = [&](int rc, float g) { S[rc * vi + w] = g; };
             if (a.nll_target) {
                 const float *tn = a.nll_target + (int64_t)n * P * V * 2;
                 const float inv_cnt = 1.0f / (float)(P * vi);
@@ -1115,13 +1110,33 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
                     }
                 }
             }
-            // the position-major fp32 copy for the weight-gradient GEMM: the lane's quad of every tile, read back from
-            // the pieces (h + m + l is exact), one 16-byte store each -- a scattered 4-byte store per value cost 20 us
+            // quads: the lane's (position, channel quad) of every tile from S (plane (ch, row) = row ch*C + row of the
+            // array), held in registers while S is wiped (the m / l images must be zero outside the interior), then
+            // split into the three images and stored position-major for the weight-gradient GEMM (16 bytes per lane: a
+            // scattered 4-byte store and three 2-byte LDS stores per value cost 20 us)
+            // (the registers of the running input gradient are free here: the output conv's chain starts from zero)
+            __builtin_amdgcn_wave_barrier();
+            f32x4 (&qd)[kX6Tiles] = dcur;
+#pragma unroll
+            for (int t = 0; t < kX6Tiles; ++t) {
+                const int p = 16 * t + nq;
+                const unsigned hw = ptab[p < npos ? p : 0];
+                const float *sq = S + ((4 * (kq < 3 ? kq : 0)) * C + (int)(hw >> 8)) * vi + (int)(hw & 0xffu);
+                qd[t] = f32x4{sq[0], sq[C * vi], sq[2 * C * vi], sq[3 * C * vi]};
+            }
+            __builtin_amdgcn_wave_barrier();
+            {
+                uint4 *z4 = reinterpret_cast<uint4 *>(img + lg.PL);
+                for (int e = lane; e < (2 * lg.PL) >> 4; e += 64) z4[e] = make_uint4(0u, 0u, 0u, 0u);
+            }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int t = 0; t < kX6Tiles; ++t) {
                 const int rc_ = rec_of(t);
-                if (rc_ >= 0) reinterpret_cast<f32x4 *>(dzo)[(16 * t + nq) * 3 + kq] = cv::get4(img, (unsigned)rc_, lg.PL);
+                if (rc_ >= 0) {
+                    cv::put4(img, (unsigned)rc_, lg.PL, qd[t]);
+                    reinterpret_cast<f32x4 *>(dzo)[(16 * t + nq) * 3 + kq] = qd[t];
+                }
             }
         } else {
             // dz_l = d(a_{l+1}) * prelu'(z_l): z_l and dz_l are position-major [pos][12] in HBM, the lane's quad of tile t
