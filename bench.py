@@ -166,7 +166,7 @@ def bytes_per_window(v):
 # convs 1,520 V; the aggregation 80 V^2 with its 2x re-association saving not credited)
 KERNELS = {
     "model_fwd": [("stgcn_agg_kernel (x A, colsum A: the read of A)", lambda v: 80 * v * v, "hbm"),
-                  ("txp_fwd_wave_kernel (st_gcn block + TXP-CNN forward)", lambda v: 62000 * v, "mfma")],
+                  ("txp_fwd_x6_kernel / txp_fwd_wave_kernel (st_gcn block + TXP-CNN forward)", lambda v: 62000 * v, "mfma")],
     "model_bwd": [("txp_bwd_x6_kernel / txp_bwd_wave_kernel (loss gradient + TXP input-gradient chain + st_gcn block "
                    "backward)", lambda v: 60480 * v + 2 * 1520 * v + 80 * v * v, "mfma"),
                   ("txp_wgrad_bf16_kernel / txp_wgrad_kernel (TXP weight / bias gradients)", lambda v: 60480 * v, "mfma"),
@@ -181,8 +181,8 @@ def issued_bf16_flop(kernel, v):
     (V > 32, bf16 storage: the library then runs txp_bwd_wave_kernel / txp_wgrad_kernel)."""
     if v > 32:
         return None
-    if kernel.startswith("txp_bwd_x6"):
-        return 6 * ((5 * v + 15) // 16) * 24 * 16384          # six input-gradient convs, 24 MFMAs per 16-position tile
+    if kernel.startswith("txp_fwd_x6") or kernel.startswith("txp_bwd_x6"):
+        return 6 * ((5 * v + 15) // 16) * 24 * 16384          # six convs, 24 MFMAs per 16-position tile
     if kernel.startswith("txp_wgrad_bf16"):
         return 6 * ((5 * v + 31) // 32) * 57 * 16384          # six layers, 9 taps x 6 products + 3 bias MFMAs per 32 positions
     return None
