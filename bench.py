@@ -59,6 +59,9 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="bf16: bf16 STORAGE of saved activations / hand-offs (fp32 accumulate, fp32 parameters)")
     ap.add_argument("--wg-path", action="store_true", help="force the workgroup-per-scene kernels (STG_OPT_WG_PATH)")
+    ap.add_argument("--f32-mfma", action="store_true",
+                    help="A/B: the fp32-MFMA convolution / weight-gradient kernels instead of the exact bf16-pipe ones "
+                         "(STG_OPT_F32_MFMA)")
     ap.add_argument("--wg-waves", type=int, default=0, help="waves per scene of the workgroup-per-scene kernels (0 auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
@@ -298,6 +301,7 @@ def main():
     from social_stgcnn_amd.model import social_stgcnn
     from social_stgcnn_amd.trainer import Trainer, broadcast_module
     ops.OPTIONS["wg_path"] = bool(args.wg_path)
+    ops.OPTIONS["f32_mfma"] = bool(args.f32_mfma)
     ops.OPTIONS["wg_waves"] = int(args.wg_waves)
     if args.dtype == "bf16":
         if "bf16_store" not in ops.OPTIONS:
@@ -430,7 +434,8 @@ def main():
                     row = {"kernel": name, "entry": "stg_" + entry, "launch_ms": t, "bound": bound,
                            "algorithmic_flop_per_launch": fl,
                            "achieved_tflops": fl / (t * 1e-3) / 1e12 if t > 0 else None}
-                    iss = [issued_bf16_flop(name, c) for c in per_scene] if args.dtype == "f32" else [None]
+                    iss = ([issued_bf16_flop(name, c) for c in per_scene]
+                           if args.dtype == "f32" and not args.f32_mfma and not args.wg_path else [None])
                     if t > 0 and all(q is not None for q in iss):
                         ifl = sum(iss) / len(dsets)
                         row["issued"] = {"instruction": "v_mfma_f32_16x16x32_bf16 (exact three-piece operands: six bf16 "

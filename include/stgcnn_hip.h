@@ -121,6 +121,9 @@ typedef struct {
                               /* backward's kernels (TXP planes a_l, pre-activations z_l, dz_l): half the bytes; compute,    */
                               /* accumulation, parameters, inputs and V_pred stay fp32 (the forward result is unchanged).    */
                               /* Wave-per-scene path only (one st_gcn block, V <= 68).                                       */
+#define STG_OPT_F32_MFMA 16   /* run the TXP convolutions and the weight-gradient GEMM on v_mfma_f32_16x16x4_f32 (the round-1 kernels)
+                               * where the default uses v_mfma_f32_16x16x32_bf16 with exact three-piece operands (V <= 32, fp32
+                               * storage): same accuracy class, for A/B measurements                                            */
 #define STG_OPT_WAVE_PATH 4   /* keep the wave-per-scene kernels for small batches too (default: batches of fewer than  */
                               /* 768 scenes of <= 40 pedestrians run the workgroup kernels, several waves per scene)     */
 

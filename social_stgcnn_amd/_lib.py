@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 DIAG = os.environ.get("STG_USE_DIAG_LIB", "0") not in ("", "0")
 LIB_PATH = os.path.join(CSRC, "libstgcnn_hip_diag.so" if DIAG else "libstgcnn_hip.so")
 ABI_VERSION = 6
-OPT_WG_PATH, OPT_SPLIT_BF16, OPT_WAVE_PATH, OPT_BF16_STORE = 1, 2, 4, 8
+OPT_WG_PATH, OPT_SPLIT_BF16, OPT_WAVE_PATH, OPT_BF16_STORE, OPT_F32_MFMA = 1, 2, 4, 8, 16
 EUNSUPPORTED = -2            # STG_EUNSUPPORTED
 
 c_f = ctypes.c_void_p          # device pointers travel as void*

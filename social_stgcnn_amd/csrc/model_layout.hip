@@ -29,7 +29,7 @@ int make_layout(const stg_model_desc *d, ModelLayout *lay) {
     l.bn_mode = d->bn_mode;
     l.eps = d->bn_eps;
     l.momentum = d->bn_momentum;
-    STG_REQUIRE((d->flags & ~(STG_OPT_WG_PATH | STG_OPT_SPLIT_BF16 | STG_OPT_WAVE_PATH | STG_OPT_BF16_STORE)) == 0, STG_EINVAL,
+    STG_REQUIRE((d->flags & ~(STG_OPT_WG_PATH | STG_OPT_SPLIT_BF16 | STG_OPT_WAVE_PATH | STG_OPT_BF16_STORE | STG_OPT_F32_MFMA)) == 0, STG_EINVAL,
                 "unknown flags 0x%x", d->flags);
     STG_REQUIRE(d->wg_waves == 0 || d->wg_waves == 1 || d->wg_waves == 2 || d->wg_waves == 4 || d->wg_waves == 8,
                 STG_EINVAL, "wg_waves=%d (0 auto, 1, 2, 4, 8)", d->wg_waves);

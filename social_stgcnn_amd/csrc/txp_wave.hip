@@ -1422,7 +1422,7 @@ static int mix_grid(size_t lds_bytes, int N) {
 }
 
 bool txp_fwd_x6_fits(const ModelLayout &L, int V) {
-    return L.n_txp > 0 && V <= 16 * kF6Tiles / C && !(L.flags & STG_OPT_BF16_STORE) && L.n_blocks == 1 &&
+    return L.n_txp > 0 && V <= 16 * kF6Tiles / C && !(L.flags & (STG_OPT_BF16_STORE | STG_OPT_F32_MFMA)) && L.n_blocks == 1 &&
            L.blk[0].cin == Cfg::CIN0 && !diag_env("STG_FWD_F32", 0);
 }
 
@@ -1472,8 +1472,8 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
 }
 
 bool txp_bwd_x6_fits(const ModelLayout &L, int V) {
-    return L.n_txp > 0 && V <= 16 * kX6Tiles / C && !(L.flags & (STG_OPT_BF16_STORE | STG_OPT_SPLIT_BF16)) &&
-           !diag_env("STG_BWD_F32", 0);
+    return L.n_txp > 0 && V <= 16 * kX6Tiles / C &&
+           !(L.flags & (STG_OPT_BF16_STORE | STG_OPT_SPLIT_BF16 | STG_OPT_F32_MFMA)) && !diag_env("STG_BWD_F32", 0);
 }
 int64_t txp_bwd_x6_wp_floats(const ModelLayout &L) { return (int64_t)(L.L + 1) * cv::kWpDwords; }
 int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {

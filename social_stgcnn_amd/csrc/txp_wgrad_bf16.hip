@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kWavesB * 64, 6) void txp_wgrad_bf16_kernel(const W
 
 // whole-scene fp32 work items only (V <= kWgradChunkV, no bf16 storage): everything else runs txp_wgrad.hip
 bool wgrad_bf16_fits(const ModelLayout &L, int V) {
-    return V <= kWgradChunkV && !(L.flags & STG_OPT_BF16_STORE) && 2 * (size_t)image_bytes(V) * 2 <= (size_t)kLdsBytes;
+    return V <= kWgradChunkV && !(L.flags & (STG_OPT_BF16_STORE | STG_OPT_F32_MFMA)) && 2 * (size_t)image_bytes(V) * 2 <= (size_t)kLdsBytes;
 }
 
 void wgrad_bf16_geom(WgradGeom *g, int V) {

@@ -184,14 +184,16 @@ class FlatPack:
 #               most of the chip's wave slots empty)
 #   bf16_store  bf16 storage of the saved TXP activations and of the dz hand-off (STG_OPT_BF16_STORE): fp32 forward
 #               result, ~1e-3 relative error in the TXP weight / slope gradients; wave-per-scene path only
-OPTIONS = {"wg_path": False, "split_bf16": False, "wg_waves": 0, "wave_path": False, "bf16_store": False}
+#   f32_mfma    the fp32-MFMA kernels where the default runs the exact bf16-pipe ones (STG_OPT_F32_MFMA): A/B measurements
+OPTIONS = {"wg_path": False, "split_bf16": False, "wg_waves": 0, "wave_path": False, "bf16_store": False, "f32_mfma": False}
 
 
 def make_desc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, use_mdn, training,
               eps=1e-5, momentum=0.1):
     flags = ((_lib.OPT_WG_PATH if OPTIONS["wg_path"] else 0) | (_lib.OPT_SPLIT_BF16 if OPTIONS["split_bf16"] else 0)
              | (_lib.OPT_WAVE_PATH if OPTIONS["wave_path"] else 0)
-             | (_lib.OPT_BF16_STORE if OPTIONS["bf16_store"] else 0))
+             | (_lib.OPT_BF16_STORE if OPTIONS["bf16_store"] else 0)
+             | (_lib.OPT_F32_MFMA if OPTIONS["f32_mfma"] else 0))
     return ModelDesc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, 1 if use_mdn else 0,
                      1 if training else 0, eps, momentum, flags, int(OPTIONS["wg_waves"]))
 

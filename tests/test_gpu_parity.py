@@ -844,3 +844,37 @@ def test_split_bf16_input_gradient_variant(dev, monkeypatch):
     for v in (3, 17, 57):
         test_train_forward_backward_golden(dev, v)
     test_ragged_batch_is_order_invariant(dev)
+
+
+def test_bf16_pipe_kernels_agree_with_the_fp32_mfma_kernels(dev, monkeypatch):
+    """The default convolution / weight-gradient kernels (v_mfma_f32_16x16x32_bf16, exact three-piece operands) against
+    the fp32-MFMA kernels (STG_OPT_F32_MFMA) on one ragged 96-scene batch: same accuracy class -- V_pred and every
+    gradient agree to a few fp32 roundings of the accumulated sums."""
+    import bench
+    from social_stgcnn_amd import ops
+    from social_stgcnn_amd.model import social_stgcnn
+    from social_stgcnn_amd.trainer import Trainer
+    n, v = 96, 32
+    obs_rel, target = bench.synth_scenes(n, v, 44)
+    nodes, adj = ops.adj_build(torch.from_numpy(obs_rel).to(dev))
+    x, tgt = nodes.permute(0, 3, 1, 2), torch.from_numpy(target).to(dev)
+    peds = torch.randint(1, v + 1, (n,), generator=torch.Generator().manual_seed(3)).to(torch.int32)
+    peds[:8] = v
+    peds = peds.to(dev)
+    w = torch.full((n,), 1.0 / n, device=dev)
+    out = {}
+    for f32 in (False, True):
+        monkeypatch.setitem(ops.OPTIONS, "f32_mfma", f32)
+        torch.manual_seed(21)
+        m = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3, pred_seq_len=12).to(dev).train()
+        tr = Trainer(m, lr=0.01)
+        total, losses, y = tr.forward_backward(x, adj, tgt, peds, w)
+        out[f32] = (y.cpu(), losses.cpu(), {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None})
+    ya, la, ga = out[False]
+    yb, lb, gb = out[True]
+    assert float((ya - yb).abs().max()) < 5e-6 * max(1.0, float(yb.abs().max()))
+    assert torch.allclose(la, lb, rtol=1e-5, atol=1e-6)
+    gmax = max(float(g.abs().max()) for g in gb.values())
+    for k, g in gb.items():
+        scale = max(0.05 * gmax, float(g.abs().max()))
+        assert float((ga[k] - g).abs().max()) <= 2e-5 * scale, (k, float((ga[k] - g).abs().max()), scale)
