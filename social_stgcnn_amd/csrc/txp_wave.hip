@@ -464,7 +464,8 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
     float *statn = a.stats ? a.stats + (int64_t)n * L.stat_floats : nullptr;
     unsigned char *img = reinterpret_cast<unsigned char *>(region);
     const cv::LaneGeom lg = cv::lane_geom(vi, kF6Slots);
-    const int SWs = vi + 2;                            // row stride (positions) of the saved planes
+    const bool bf16 = (L.flags & STG_OPT_BF16_STORE) != 0;        // bf16 storage of the saved planes / pre-activations
+    const int SWs = save_sw(vi, bf16), VWs = save_vw(vi, bf16);   // row strides (positions) of the saved arrays
 
     // ---- st_gcn block (model.py:145-155), column mode: lane = pedestrian; zeroes the image, builds the position table
     {
@@ -483,16 +484,16 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
                     const f32x4 v4 = {sv[(4 * q + 0) * C + row], sv[(4 * q + 1) * C + row], sv[(4 * q + 2) * C + row],
                                       sv[(4 * q + 3) * C + row]};
                     cv::put4(img, (unsigned)(cv::pos_off(vi, 1 + row, lane) + 8 * q), lg.PL, v4);
-                    if (d2) reinterpret_cast<f32x4 *>(d2)[(row * SWs + lane + 1) * 3 + q] = v4;
+                    if (d2) store_vec4(d2, (row * SWs + lane + 1) * 3 + q, v4, bf16);
                 }
-                if (d2) reinterpret_cast<f32x4 *>(d2)[(row * SWs + lane + 1) * 3 + 2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (d2) store_vec4(d2, (row * SWs + lane + 1) * 3 + 2, f32x4{0.f, 0.f, 0.f, 0.f}, bf16);
             }
         }
         if (wsn && lane < 2 * C * 3) {
             // zero border columns of the saved planes a_0 .. a_L (the weight-gradient GEMM reads them)
-            const int b = lane / 3, q = lane - b * 3, pos = (b >> 1) * SWs + ((b & 1) ? SWs - 1 : 0);
+            const int b = lane / 3, q = lane - b * 3, pos = (b >> 1) * SWs + ((b & 1) ? vi + 1 : 0);
             for (int l = 0; l <= L.L; ++l)
-                reinterpret_cast<f32x4 *>(wsn + ws_plane_off(L, V, l))[pos * 3 + q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                store_vec4(wsn + ws_plane_off(L, V, l), pos * 3 + q, f32x4{0.f, 0.f, 0.f, 0.f}, bf16);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -536,8 +537,8 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
                         for (int r = 0; r < 4; ++r) v4[r] = (z[r] > 0.f ? z[r] : alpha * z[r]) + (l > 0 ? av[t][r] : 0.f);
                         av[t] = v4;
                         if (zs) {
-                            reinterpret_cast<f32x4 *>(zs)[tl.pos * 3 + kq] = z;
-                            reinterpret_cast<f32x4 *>(ps)[(tl.h * SWs + tl.w + 1) * 3 + kq] = v4;
+                            store_vec4(zs, (tl.h * VWs + tl.w) * 3 + kq, z, bf16);
+                            store_vec4(ps, (tl.h * SWs + tl.w + 1) * 3 + kq, v4, bf16);
                         }
                     }
                 }
@@ -1042,6 +1043,14 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
     const float *dyn = a.dy + (int64_t)n * (C * P) * V;
     unsigned char *img = reinterpret_cast<unsigned char *>(region);
     const cv::LaneGeom lg = cv::lane_geom(vi, kX6Slots);
+    const bool bf16 = (L.flags & STG_OPT_BF16_STORE) != 0;        // bf16 storage of z_l (read) and dz_l (written)
+    const int VWs = save_vw(vi, bf16);                             // row stride (positions) of the saved z_l / dz_l
+    // vector index of the lane's quad of tile t in those arrays (fp32: rows of vi positions, i.e. (16 t + n) * 3 + kq)
+    auto quad_of = [&](int t) -> int {
+        const int p = 16 * t + nq;
+        const unsigned hw = ptab[p < npos ? p : 0];
+        return ((int)(hw >> 8) * VWs + (int)(hw & 0xffu)) * 3 + kq;
+    };
     {
         uint4 *z4 = reinterpret_cast<uint4 *>(img);
         for (int e = lane; e < (3 * lg.PL) >> 4; e += 64) z4[e] = make_uint4(0u, 0u, 0u, 0u);
@@ -1135,7 +1144,7 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
                 const int rc_ = rec_of(t);
                 if (rc_ >= 0) {
                     cv::put4(img, (unsigned)rc_, lg.PL, qd[t]);
-                    reinterpret_cast<f32x4 *>(dzo)[(16 * t + nq) * 3 + kq] = qd[t];
+                    store_vec4(dzo, quad_of(t), qd[t], bf16);
                 }
             }
         } else {
@@ -1154,7 +1163,7 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
             for (int t = 0; t < kX6Tiles; ++t) rec[t] = rec_of(t);
 #pragma unroll
             for (int t = 0; t < kX6Tiles; ++t)
-                zv[t] = rec[t] >= 0 ? reinterpret_cast<const f32x4 *>(zl)[(16 * t + nq) * 3 + kq] : f32x4{1.f, 1.f, 1.f, 1.f};
+                zv[t] = rec[t] >= 0 ? load_vec4(zl, quad_of(t), bf16) : f32x4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int t = 0; t < kX6Tiles; ++t) {
                 if (rec[t] >= 0) {
@@ -1170,7 +1179,7 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
                         dzv[r] = dz;
                     }
                     cv::put4(img, (unsigned)rec[t], lg.PL, dzv);
-                    reinterpret_cast<f32x4 *>(dzo)[(16 * t + nq) * 3 + kq] = dzv;
+                    store_vec4(dzo, quad_of(t), dzv, bf16);
                 }
             }
             slope_acc = wave_sum(slope_acc);
@@ -1422,7 +1431,7 @@ static int mix_grid(size_t lds_bytes, int N) {
 }
 
 bool txp_fwd_x6_fits(const ModelLayout &L, int V) {
-    return L.n_txp > 0 && V <= 16 * kF6Tiles / C && !(L.flags & (STG_OPT_BF16_STORE | STG_OPT_F32_MFMA)) && L.n_blocks == 1 &&
+    return L.n_txp > 0 && V <= 16 * kF6Tiles / C && !(L.flags & STG_OPT_F32_MFMA) && L.n_blocks == 1 &&
            L.blk[0].cin == Cfg::CIN0 && !diag_env("STG_FWD_F32", 0);
 }
 
@@ -1473,7 +1482,7 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
 
 bool txp_bwd_x6_fits(const ModelLayout &L, int V) {
     return L.n_txp > 0 && V <= 16 * kX6Tiles / C &&
-           !(L.flags & (STG_OPT_BF16_STORE | STG_OPT_SPLIT_BF16 | STG_OPT_F32_MFMA)) && !diag_env("STG_BWD_F32", 0);
+           !(L.flags & (STG_OPT_SPLIT_BF16 | STG_OPT_F32_MFMA)) && !diag_env("STG_BWD_F32", 0);
 }
 int64_t txp_bwd_x6_wp_floats(const ModelLayout &L) { return (int64_t)(L.L + 1) * cv::kWpDwords; }
 int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {

@@ -304,7 +304,7 @@ bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
     g->lds = lds;
     g->bf16mma = wgrad_bf16_fits(L, V) && !diag_env("STG_WGRAD_F32", 0);
     if (g->bf16mma) {
-        wgrad_bf16_geom(g, V);
+        wgrad_bf16_geom(g, L, V);
         per_cu = 2;
     }
     int total = kNumCU * per_cu;                       // resident workgroups on the chip

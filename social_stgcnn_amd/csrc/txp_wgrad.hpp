@@ -56,7 +56,7 @@ struct WgradArgs {
 int launch_txp_wgrad(const WgradArgs &w, const WgradGeom &g, hipStream_t st);
 // txp_wgrad_bf16.hip: the same GEMM on the bf16 matrix pipe with exact three-piece operands
 bool wgrad_bf16_fits(const ModelLayout &L, int V);
-void wgrad_bf16_geom(WgradGeom *g, int V);
+void wgrad_bf16_geom(WgradGeom *g, const ModelLayout &L, int V);
 int launch_txp_wgrad_bf16(const WgradArgs &w, const WgradGeom &g, hipStream_t st);
 
 }  // namespace stg

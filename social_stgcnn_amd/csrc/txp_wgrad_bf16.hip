@@ -34,8 +34,14 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // bytes of one LDS image for batch width V: plane (C+2)(V+2) records, dz C*V records + one zero record
-__host__ __device__ inline int image_a_recs(int V) { return (C + 2) * (V + 2); }
-__host__ __device__ inline int image_bytes(int V) { return ((image_a_recs(V) + C * V + 1) * kRec + 15) & ~15; }
+// (bf16 storage, STG_OPT_BF16_STORE: the saved rows are padded to an even number of positions -- save_sw / save_vw)
+__host__ __device__ inline int image_a_recs(int V, bool bf) { return (C + 2) * save_sw(V, bf); }
+__host__ __device__ inline int image_bytes(int V, bool bf) {
+    return ((image_a_recs(V, bf) + C * save_vw(V, bf) + 1) * kRec + 15) & ~15;
+}
+
+template <bool BF> struct StageType { typedef f32x4 type; };
+template <> struct StageType<true> { typedef unsigned type __attribute__((ext_vector_type(2))); };
 
 struct Item {
     int vi;
@@ -75,7 +81,7 @@ __device__ __forceinline__ f32x4 mma(const u32x2 (&a)[2], const u32x2 (&b)[2], c
                                                    0, 0, 0);
 }
 
-template <int CINL>
+template <int CINL, bool BF>
 __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32_t *__restrict__ order,
                                                  const int32_t *__restrict__ order_peds,
                                                  const int32_t *__restrict__ num_peds, int layer, unsigned char *sm, int wg,
@@ -86,7 +92,7 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     const int ks = wave >> 1, hf = wave & 1;                    // K-step and tap half of this wave
     const int kg = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;   // operand chunk, row and column quad of the tr reads
     const int nq = lane & 15, kq = lane >> 4;                   // accumulator: column (input channel), row quad
-    const int img = image_bytes(V);
+    const int img = image_bytes(V, BF);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)sm;
     const int items = a.N;
     const int64_t plane_off = ws_plane_off(L, V, layer), dzs_floats = dz_slot(V);
@@ -125,30 +131,35 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     // re-read the first bytes of the workspace), so `landed` is one fixed s_waitcnt vmcnt(2); the destination is a
     // read-write operand, which keeps a refilled set in the registers it already had (a renamed set would be copied
     // at the loop edge -- while its data is still in flight).
-    struct Stage { f32x4 v[2]; };
+    // bf16 storage (BF): the saved arrays ARE the h pieces (24-byte positions, 8-byte quads); m = l = 0 and only the
+    // h x h product is issued -- a task moves 8 bytes, nothing is split.
+    using StageV = typename StageType<BF>::type;       // what one task fetches: 16 bytes (fp32 quad) or 8 (bf16 quad)
+    struct Stage { StageV v[2]; };
     auto load = [&](const Item &it, Stage &s) {
         const bool live = it.valid && !STG_SKIP(a, 64);
-        const int na = live ? C * (it.vi + 2) * 3 : 0, nz = live ? C * it.vi * 3 : 0;
+        const int na = live ? C * save_sw(it.vi, BF) * 3 : 0, nz = live ? C * save_vw(it.vi, BF) * 3 : 0;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + u * kWavesB * 64;
-            const float *src = e < na ? it.pl + 4 * e : (e < na + nz ? it.dz + 4 * (e - na) : a.ws);
-            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(s.v[u]) : "v"(src) : "memory");
+            constexpr int TF = BF ? 2 : 4;             // floats per task
+            const float *src = e < na ? it.pl + TF * e : (e < na + nz ? it.dz + TF * (e - na) : a.ws);
+            if constexpr (BF) asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(s.v[u]) : "v"(src) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(s.v[u]) : "v"(src) : "memory");
         }
     };
     // the set's loads have landed once only the two loads of the other set are outstanding
     auto landed = [&](Stage &s) { asm volatile("s_waitcnt vmcnt(2)" : "+v"(s.v[0]), "+v"(s.v[1])::"memory"); };
     auto convert = [&](const Item &it, const Stage &s, unsigned char *buf) {
         if (!it.valid || STG_SKIP(a, 64)) return;
-        const int SWa = it.vi + 2, na = C * SWa * 3, nz = C * it.vi * 3;
-        unsigned char *dzimg = buf + image_a_recs(V) * kRec;
+        const int SWa = save_sw(it.vi, BF), VWz = save_vw(it.vi, BF), na = C * SWa * 3, nz = C * VWz * 3;
+        unsigned char *dzimg = buf + image_a_recs(V, BF) * kRec;
         // zero border rows of the plane image (rows 0 and C + 1) and the zero record behind dz: 8-byte stores
         constexpr int U = kRec / 8;
         for (int e = tid; e < 2 * SWa * U + U; e += kWavesB * 64) {
             unsigned char *dst;
             if (e < SWa * U) dst = buf + e * 8;
             else if (e < 2 * SWa * U) dst = buf + (C + 1) * SWa * kRec + (e - SWa * U) * 8;
-            else dst = dzimg + C * it.vi * kRec + (e - 2 * SWa * U) * 8;
+            else dst = dzimg + C * VWz * kRec + (e - 2 * SWa * U) * 8;
             *reinterpret_cast<uint2 *>(dst) = make_uint2(0u, 0u);
         }
 #pragma unroll
@@ -159,23 +170,27 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
                 const int f = isz ? e - na : e, rec = f / 3, q = f - rec * 3;
                 // plane rows h = 0..C-1 land in image rows 1..C: record index + SWa
                 unsigned char *dst = (isz ? dzimg + rec * kRec : buf + (rec + SWa) * kRec) + 8 * q;
-                uint2 ph, pm, pl;
-                cv::split_pack4(s.v[u], ph, pm, pl);
-                *reinterpret_cast<uint2 *>(dst) = ph;
-                *reinterpret_cast<uint2 *>(dst + kPiece) = pm;
-                *reinterpret_cast<uint2 *>(dst + 2 * kPiece) = pl;
+                if constexpr (BF) {
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(s.v[u].x, s.v[u].y);
+                } else {
+                    uint2 ph, pm, pl;
+                    cv::split_pack4(s.v[u], ph, pm, pl);
+                    *reinterpret_cast<uint2 *>(dst) = ph;
+                    *reinterpret_cast<uint2 *>(dst + kPiece) = pm;
+                    *reinterpret_cast<uint2 *>(dst + 2 * kPiece) = pl;
+                }
             }
         }
     };
     // ---- this wave's K-step of the scene staged in `buf` ------------------------------------------------------------
     auto compute = [&](const Item &it, unsigned buf_off) {
         if (!it.valid || STG_SKIP(a, 128)) return;
-        const int vi = it.vi, npos = C * vi, SWa = vi + 2;
+        const int vi = it.vi, npos = C * vi, SWa = save_sw(vi, BF), VWz = save_vw(vi, BF);
         if (32 * ks >= npos) return;
         unsigned inv = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)vi));
         while (inv * (unsigned)vi < 65536u) ++inv;
         while ((inv - 1u) * (unsigned)vi >= 65536u) --inv;
-        const unsigned abase = lds0 + buf_off, zbase = abase + image_a_recs(V) * kRec;
+        const unsigned abase = lds0 + buf_off, zbase = abase + image_a_recs(V, BF) * kRec;
         unsigned za[2], aa[2];
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
@@ -186,13 +201,33 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
             const bool ok = p < npos;
             const int pc = ok ? p : 0;
             const int hh = (int)(((unsigned)pc * inv) >> 16), ww = pc - hh * vi;
-            za[rd] = zbase + (ok ? p : npos) * kRec + 8 * cp;                         // past the end: the zero record
+            za[rd] = zbase + (ok ? hh * VWz + ww : C * VWz) * kRec + 8 * cp;          // past the end: the zero record
             aa[rd] = abase + (ok ? ((hh + 1) * SWa + (ww + 1)) * kRec : SWa * kRec + kRec) + 8 * cp;
         }
         // one operand register set: the LDS latency of a tap's six reads is covered by the other four waves of the SIMD
         // (five resident waves need <= 96 VGPRs; a second operand set spilled)
         const int ntap = hf == 0 ? 5 : 4;                  // tap tiles of this half (the bias tile needs no plane operand)
         Op3 dzo, ao;
+        if (BF) {
+            // bf16 storage: one piece, one product per tap
+            dzo.h[0] = tr_read(za[0], 0);
+            dzo.h[1] = tr_read(za[1], 0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                if (k < ntap) {
+                    const int tap = hf * 5 + k;
+                    const int shift = ((tap / 3 - 1) * SWa + (tap % 3 - 1)) * kRec;
+                    ao.h[0] = tr_read(aa[0] + shift, 0);
+                    ao.h[1] = tr_read(aa[1] + shift, 0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ao.h[0]), "+v"(ao.h[1]), "+v"(dzo.h[0]), "+v"(dzo.h[1])::"memory");
+                    acc[k] = mma(dzo.h, ao.h, acc[k]);
+                } else {
+                    const u32x2 one[2] = {u32x2{0x3f803f80u, 0x3f803f80u}, u32x2{0x3f803f80u, 0x3f803f80u}};
+                    acc[k] = mma(dzo.h, one, acc[k]);
+                }
+            }
+            return;
+        }
         read_op(za[0], za[1], dzo);
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -226,7 +261,7 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     Item q0 = finish(fetch(0)), q1 = finish(fetch(1)), q2 = finish(fetch(2));
     Raw nxt = fetch(3);
     Stage sa, sb;                                      // sa: the scene converted next, sb: the one after it
-    sa.v[0] = sa.v[1] = sb.v[0] = sb.v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    sa.v[0] = sa.v[1] = sb.v[0] = sb.v[1] = StageV{};
     load(q0, sa);
     load(q1, sb);
     for (int r = 0; r < rounds; r += 2) {
@@ -280,6 +315,7 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     }
 }
 
+template <bool BF>
 __global__ __launch_bounds__(kWavesB * 64, 6) void txp_wgrad_bf16_kernel(const WgradArgs a, const int32_t *__restrict__ order,
                                                                          const int32_t *__restrict__ order_peds,
                                                                          const int32_t *__restrict__ num_peds) {
@@ -289,21 +325,22 @@ __global__ __launch_bounds__(kWavesB * 64, 6) void txp_wgrad_bf16_kernel(const W
     const int wg = (int)blockIdx.x - a.wg_begin[layer];
     const int nwg = a.wg_begin[layer + 1] - a.wg_begin[layer];
     if (layer == 0)
-        wgrad_bf16_layer<Cfg::T>(a, order, order_peds, num_peds, layer, smb, wg, nwg);
+        wgrad_bf16_layer<Cfg::T, BF>(a, order, order_peds, num_peds, layer, smb, wg, nwg);
     else
-        wgrad_bf16_layer<Cfg::P>(a, order, order_peds, num_peds, layer, smb, wg, nwg);
+        wgrad_bf16_layer<Cfg::P, BF>(a, order, order_peds, num_peds, layer, smb, wg, nwg);
 }
 
 }  // namespace
 
-// whole-scene fp32 work items only (V <= kWgradChunkV, no bf16 storage): everything else runs txp_wgrad.hip
+// whole-scene work items only (V <= kWgradChunkV): larger scenes (column chunks) run txp_wgrad.hip
 bool wgrad_bf16_fits(const ModelLayout &L, int V) {
-    return V <= kWgradChunkV && !(L.flags & (STG_OPT_BF16_STORE | STG_OPT_F32_MFMA)) && 2 * (size_t)image_bytes(V) * 2 <= (size_t)kLdsBytes;
+    const bool bf = (L.flags & STG_OPT_BF16_STORE) != 0;
+    return V <= kWgradChunkV && !(L.flags & STG_OPT_F32_MFMA) && 2 * (size_t)image_bytes(V, bf) * 2 <= (size_t)kLdsBytes;
 }
 
-void wgrad_bf16_geom(WgradGeom *g, int V) {
+void wgrad_bf16_geom(WgradGeom *g, const ModelLayout &L, int V) {
     const size_t row = (size_t)((Cfg::P * Cfg::P * 9 + Cfg::P + 3) & ~3) * sizeof(float) * kWavesB;
-    size_t lds = 2 * (size_t)image_bytes(V);
+    size_t lds = 2 * (size_t)image_bytes(V, (L.flags & STG_OPT_BF16_STORE) != 0);
     if (lds < row) lds = row;
     g->waves = kWavesB;
     g->nbuf = 2;
@@ -312,10 +349,13 @@ void wgrad_bf16_geom(WgradGeom *g, int V) {
 
 int launch_txp_wgrad_bf16(const WgradArgs &w, const WgradGeom &g, hipStream_t st) {
     const dim3 grid(g.grid), block(kWavesB * 64);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_wgrad_bf16_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+    const bool bf = (w.lay.flags & STG_OPT_BF16_STORE) != 0;
+    const void *fn = bf ? reinterpret_cast<const void *>(&txp_wgrad_bf16_kernel<true>)
+                        : reinterpret_cast<const void *>(&txp_wgrad_bf16_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
     if (e != hipSuccess) return hip_fail(e, "txp_wgrad_bf16: hipFuncSetAttribute");
-    hipLaunchKernelGGL(txp_wgrad_bf16_kernel, grid, block, g.lds, st, w, w.order, w.order_peds, w.num_peds);
+    if (bf) hipLaunchKernelGGL(txp_wgrad_bf16_kernel<true>, grid, block, g.lds, st, w, w.order, w.order_peds, w.num_peds);
+    else hipLaunchKernelGGL(txp_wgrad_bf16_kernel<false>, grid, block, g.lds, st, w, w.order, w.order_peds, w.num_peds);
     STG_LAUNCH_CHECK("txp_wgrad_bf16");
     return STG_OK;
 }
