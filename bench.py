@@ -59,6 +59,8 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="bf16: bf16 STORAGE of saved activations / hand-offs (fp32 accumulate, fp32 parameters)")
     ap.add_argument("--wg-path", action="store_true", help="force the workgroup-per-scene kernels (STG_OPT_WG_PATH)")
+    ap.add_argument("--wave-path", action="store_true",
+                    help="keep the wave-per-scene kernels for a small batch too (STG_OPT_WAVE_PATH)")
     ap.add_argument("--f32-mfma", action="store_true",
                     help="A/B: the fp32-MFMA convolution / weight-gradient kernels instead of the exact bf16-pipe ones "
                          "(STG_OPT_F32_MFMA)")
@@ -302,6 +304,7 @@ def main():
     from social_stgcnn_amd.trainer import Trainer, broadcast_module
     ops.OPTIONS["wg_path"] = bool(args.wg_path)
     ops.OPTIONS["f32_mfma"] = bool(args.f32_mfma)
+    ops.OPTIONS["wave_path"] = bool(args.wave_path)
     ops.OPTIONS["wg_waves"] = int(args.wg_waves)
     if args.dtype == "bf16":
         if "bf16_store" not in ops.OPTIONS:
