@@ -451,7 +451,8 @@ def main():
             bwd_fl = sum(flops_per_window(c, fwd=False) for c in per_scene) / len(dsets)
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            if os.path.exists(tpath) and args.dataset == "synthetic" and not args.ragged and (v, n) == (32, 2048):
+            if (os.path.exists(tpath) and args.dataset == "synthetic" and not args.ragged and (v, n) == (32, 2048)
+                    and args.dtype == "f32" and not args.f32_mfma and not args.wg_path):
                 with open(tpath) as f:
                     tj = json.load(f)
                 key = dom["kernel"].split(" ")[0]
