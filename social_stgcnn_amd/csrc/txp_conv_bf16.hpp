@@ -12,9 +12,10 @@
 // overlap the epilogue's VALU work.
 //
 // Data layout (one wave's LDS image): POSITION-major records of 12 channels, one image per piece
-//     piece s, row slot r (0..7, a ring), column c (-1..vi-1):   byte  s * PL + ((r * SW + c + 1) * 12 + ch) * 2
+//     piece s, row slot r (0..7, a ring), column c (-1..vi-1):   byte  off_s + ((r * SW + c + 1) * 12 + ch) * 2
 //     SW = vi + 1: the zero column c = -1 of row r+1 doubles as the right border of row r
-//     PL == 128 (mod 256) bytes: the two pieces a 32-lane group reads in one ds_read_b64 sit on disjoint bank halves
+//     PL == 128 (mod 256) bytes (pieces at 0, PL, 2 PL + 128): the two pieces a 32-lane group reads in one ds_read_b64
+//     sit on disjoint bank halves
 // so that the (kw, ci) taps of one kernel row are 36 CONTIGUOUS bf16 of the image: K = (kh, [kw, ci] padded to 40)
 // = 15 chunks of 8, fetched as 8-byte-aligned 16-byte pieces (no im2col copies, no gathers).
 // The forward updates the image in place (model_common.hpp, txp_sci): a layer reads at slot offset 3 and writes at
@@ -52,7 +53,10 @@ __host__ __device__ inline int plane_bytes(int vi, int slots = kSlots) {
     const int r = (slots * sw(vi) + 4) * kPosBytes;
     return r + ((128 - r % 256) + 256) % 256;
 }
-__host__ __device__ inline int image_bytes(int vi, int slots = kSlots) { return 3 * plane_bytes(vi, slots); }
+// byte offset of the l piece image: 128 bytes past 2 PL, so that it too is == 128 (mod 256) away from the h image (the read
+// set [x_h | x_l] pairs those two in one ds_read_b64: at 2 PL == 0 (mod 256) its two lane groups collided on every bank)
+__host__ __device__ inline int l_off(int PL) { return 2 * PL + 128; }
+__host__ __device__ inline int image_bytes(int vi, int slots = kSlots) { return 3 * plane_bytes(vi, slots) + 128; }
 // byte offset (within a piece image) of the record of (row slot, column)
 __host__ __device__ inline int pos_off(int vi, int slot, int col) { return (slot * sw(vi) + col + 1) * kPosBytes; }
 
@@ -165,7 +169,7 @@ __device__ __forceinline__ LaneGeom lane_geom(int vi, int slots = kSlots) {
     g.PL = plane_bytes(vi, slots);
     g.RB = row_bytes(vi);
     g.c1 = ((kg & 1) ? g.PL : 0) + (kg >> 1) * 16;
-    g.d2 = (kg & 1) ? g.PL : 0;
+    g.d2 = (kg & 1) ? l_off(g.PL) - g.PL : 0;
     return g;
 }
 
@@ -237,7 +241,7 @@ struct Quad {
 __device__ __forceinline__ void read_quad(unsigned addr, int PL, Quad &q) {
     asm volatile("ds_read_b64 %0, %1" : "=v"(q.h) : "v"(addr) : "memory");
     asm volatile("ds_read_b64 %0, %1" : "=v"(q.m) : "v"(addr + PL) : "memory");
-    asm volatile("ds_read_b64 %0, %1" : "=v"(q.l) : "v"(addr + 2 * PL) : "memory");
+    asm volatile("ds_read_b64 %0, %1" : "=v"(q.l) : "v"(addr + l_off(PL)) : "memory");
 }
 // s_waitcnt lgkmcnt(CNT) tied to groups [G0, G0 + 4) (and to the residual quad): their registers are only read after it
 template <int CNT, int G0>
@@ -376,11 +380,11 @@ __device__ __forceinline__ void put4(unsigned char *lds, unsigned off, int PL, c
     split_pack4(v, ph, pm, pl);
     *reinterpret_cast<uint2 *>(lds + off) = ph;
     *reinterpret_cast<uint2 *>(lds + off + PL) = pm;
-    *reinterpret_cast<uint2 *>(lds + off + 2 * PL) = pl;
+    *reinterpret_cast<uint2 *>(lds + off + l_off(PL)) = pl;
 }
 __device__ __forceinline__ f32x4 get4(const unsigned char *lds, unsigned off, int PL) {
     const uint2 ph = *reinterpret_cast<const uint2 *>(lds + off), pm = *reinterpret_cast<const uint2 *>(lds + off + PL),
-                pl = *reinterpret_cast<const uint2 *>(lds + off + 2 * PL);
+                pl = *reinterpret_cast<const uint2 *>(lds + off + l_off(PL));
     return unsplit4(ph, pm, pl);
 }
 #endif  // __HIPCC__

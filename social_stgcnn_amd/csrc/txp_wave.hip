@@ -472,7 +472,7 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
         float sv[C * T];
         const float *agn = a.agg + n * a.agg_stride;
         stgcn_block_fwd_cols(a, blk_params, blk_buffers, L.blk[0], n, vi, wsn, statn, agn + a.agg_ax, agn + a.agg_cs, nullptr,
-                             0, region, (3 * lg.PL) >> 4, ptab, sv);
+                             0, region, cv::image_bytes(vi, kF6Slots) >> 4, ptab, sv);
         // v.view(N, T, C, V) (model.py:187): flat f = c*T+t of the block output is plane channel f / C, row f % C.  Per
         // row the lane's eight channels are two record quads; the third quad (channels 8..11) stays zero.
         float *d2 = wsn ? wsn + ws_plane_off(L, V, 0) : nullptr;
@@ -1053,7 +1053,7 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
     };
     {
         uint4 *z4 = reinterpret_cast<uint4 *>(img);
-        for (int e = lane; e < (3 * lg.PL) >> 4; e += 64) z4[e] = make_uint4(0u, 0u, 0u, 0u);
+        for (int e = lane; e < cv::image_bytes(vi, kX6Slots) >> 4; e += 64) z4[e] = make_uint4(0u, 0u, 0u, 0u);
     }
     build_ptab(ptab, vi);
     __builtin_amdgcn_wave_barrier();
@@ -1136,7 +1136,7 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
             __builtin_amdgcn_wave_barrier();
             {
                 uint4 *z4 = reinterpret_cast<uint4 *>(img + lg.PL);
-                for (int e = lane; e < (2 * lg.PL) >> 4; e += 64) z4[e] = make_uint4(0u, 0u, 0u, 0u);
+                for (int e = lane; e < (2 * lg.PL + 128) >> 4; e += 64) z4[e] = make_uint4(0u, 0u, 0u, 0u);
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll

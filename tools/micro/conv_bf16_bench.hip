@@ -25,7 +25,7 @@ __device__ __forceinline__ void zero_slot(unsigned char *lds, int slot, int vi, 
     const int lane = threadIdx.x & 63;
     const int n8 = row_bytes(vi) / 8;
     for (int s = 0; s < 3; ++s) {
-        uint2 *p = reinterpret_cast<uint2 *>(lds + s * PL + slot * row_bytes(vi) + kPosBytes);   // columns 0..vi-1 and the next border
+        uint2 *p = reinterpret_cast<uint2 *>(lds + (s == 2 ? l_off(PL) : s * PL) + slot * row_bytes(vi) + kPosBytes);   // columns 0..vi-1 and the next border
         for (int e = lane; e < n8; e += 64) p[e] = make_uint2(0u, 0u);
     }
 }
