@@ -303,6 +303,25 @@ __device__ __forceinline__ void wait_half(BHalf &b) {
                  :
                  : "memory");
 }
+// the same with a counted wait per group: LDS returns in order, so with 4 (3 - i) younger reads outstanding group i has
+// landed and its three MFMAs issue while the later groups are still in flight (call right after load_b_half)
+template <int CNT>
+__device__ __forceinline__ void wait_group(u32x2 &a0, u32x2 &a1, u32x2 &a2, u32x2 &a3) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "n"(CNT) : "memory");
+}
+template <int H>
+__device__ __forceinline__ void mma_half_counted(const u32x4 (&w)[kWpVecs], BHalf &b, f32x4 &acc) {
+#define STG_CV_W(i, cnt)                                                                  \
+    wait_group<cnt>(b.s1[i][0], b.s1[i][1], b.s2[i][0], b.s2[i][1]);                      \
+    acc = mma(w[3 * (4 * H + i) + 0], b.s1[i][0], b.s1[i][1], acc);                       \
+    acc = mma(w[3 * (4 * H + i) + 1], b.s1[i][0], b.s1[i][1], acc);                       \
+    acc = mma(w[3 * (4 * H + i) + 2], b.s2[i][0], b.s2[i][1], acc);
+    STG_CV_W(0, 12)
+    STG_CV_W(1, 8)
+    STG_CV_W(2, 4)
+    STG_CV_W(3, 0)
+#undef STG_CV_W
+}
 template <int H>
 __device__ __forceinline__ void mma_half(const u32x4 (&w)[kWpVecs], const BHalf &b, f32x4 &acc) {
 #pragma unroll

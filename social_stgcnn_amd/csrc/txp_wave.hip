@@ -521,11 +521,9 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
                 cv::BHalf b;
                 f32x4 z = binit;
                 cv::load_b_half<0>(lds_base, tl, b);
-                cv::wait_half(b);
-                cv::mma_half<0>(w, b, z);
+                cv::mma_half_counted<0>(w, b, z);
                 cv::load_b_half<1>(lds_base, tl, b);
-                cv::wait_half(b);
-                cv::mma_half<1>(w, b, z);
+                cv::mma_half_counted<1>(w, b, z);
                 if (tl.ok && kq < 3) {
                     if (is_out) {
                         // v.view(N, C, P, V) (model.py:195): the (P, C, V) conv output IS the (C, P, V) tensor
@@ -1203,11 +1201,9 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
                     cv::BHalf b;
                     f32x4 acc = keep ? dcur[t] : zero;
                     cv::load_b_half<0>(lds_base, tl, b);
-                    cv::wait_half(b);
-                    cv::mma_half<0>(w, b, acc);
+                    cv::mma_half_counted<0>(w, b, acc);
                     cv::load_b_half<1>(lds_base, tl, b);
-                    cv::wait_half(b);
-                    cv::mma_half<1>(w, b, acc);
+                    cv::mma_half_counted<1>(w, b, acc);
                     dcur[t] = acc;
                 }
             }
