@@ -276,51 +276,40 @@ __device__ __forceinline__ void mma_groups(const u32x4 (&w)[kWpVecs], const BReg
 struct BHalf {
     u32x2 s1[4][2], s2[4][2];
 };
+// The sixteen reads of a half-tile AND their s_waitcnt are ONE asm statement: the compiler never sees a register whose
+// data is still in flight, so no register-allocation decision (a copy between the read and a separate wait statement)
+// can pick up stale data.  The wave stalls at the wait either way; the SIMD's other wave covers the LDS latency.
 template <int H>
 __device__ __forceinline__ void load_b_half(unsigned lds_base, const Tile &t, BHalf &b) {
-#define STG_CV_G(i, bi, imm)                                       \
-    read16<imm>(lds_base + t.r1[bi], b.s1[i][0], b.s1[i][1]);     \
-    read16<imm>(lds_base + t.r2[bi], b.s2[i][0], b.s2[i][1]);
+    // groups 4H .. 4H+3: (base index, immediate) = (0,0) (0,32) (3,0) (1,16) | (1,48) (2,0) (2,32) (2,64)
+    const unsigned a0 = lds_base + t.r1[H == 0 ? 0 : 1], a1 = lds_base + t.r1[H == 0 ? 3 : 2], a2 = lds_base + t.r1[H == 0 ? 1 : 2];
+    const unsigned c0 = lds_base + t.r2[H == 0 ? 0 : 1], c1 = lds_base + t.r2[H == 0 ? 3 : 2], c2 = lds_base + t.r2[H == 0 ? 1 : 2];
+    // H == 0: g0 = a0+0, g1 = a0+32, g2 = a1+0, g3 = a2+16;   H == 1: g0 = a0+48, g1 = a1+0 (kernel row 2), g2 = a1+32, g3 = a1+64
     if (H == 0) {
-        STG_CV_G(0, 0, 0)
-        STG_CV_G(1, 0, 32)
-        STG_CV_G(2, 3, 0)
-        STG_CV_G(3, 1, 16)
+        asm volatile(
+            "ds_read_b64 %0, %16\n\tds_read_b64 %1, %16 offset:8\n\tds_read_b64 %2, %19\n\tds_read_b64 %3, %19 offset:8\n\t"
+            "ds_read_b64 %4, %16 offset:32\n\tds_read_b64 %5, %16 offset:40\n\tds_read_b64 %6, %19 offset:32\n\tds_read_b64 %7, %19 offset:40\n\t"
+            "ds_read_b64 %8, %17\n\tds_read_b64 %9, %17 offset:8\n\tds_read_b64 %10, %20\n\tds_read_b64 %11, %20 offset:8\n\t"
+            "ds_read_b64 %12, %18 offset:16\n\tds_read_b64 %13, %18 offset:24\n\tds_read_b64 %14, %21 offset:16\n\tds_read_b64 %15, %21 offset:24\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(b.s1[0][0]), "=&v"(b.s1[0][1]), "=&v"(b.s2[0][0]), "=&v"(b.s2[0][1]), "=&v"(b.s1[1][0]), "=&v"(b.s1[1][1]),
+              "=&v"(b.s2[1][0]), "=&v"(b.s2[1][1]), "=&v"(b.s1[2][0]), "=&v"(b.s1[2][1]), "=&v"(b.s2[2][0]), "=&v"(b.s2[2][1]),
+              "=&v"(b.s1[3][0]), "=&v"(b.s1[3][1]), "=&v"(b.s2[3][0]), "=&v"(b.s2[3][1])
+            : "v"(a0), "v"(a1), "v"(a2), "v"(c0), "v"(c1), "v"(c2)
+            : "memory");
     } else {
-        STG_CV_G(0, 1, 48)
-        STG_CV_G(1, 2, 0)
-        STG_CV_G(2, 2, 32)
-        STG_CV_G(3, 2, 64)
+        asm volatile(
+            "ds_read_b64 %0, %16 offset:48\n\tds_read_b64 %1, %16 offset:56\n\tds_read_b64 %2, %19 offset:48\n\tds_read_b64 %3, %19 offset:56\n\t"
+            "ds_read_b64 %4, %17\n\tds_read_b64 %5, %17 offset:8\n\tds_read_b64 %6, %20\n\tds_read_b64 %7, %20 offset:8\n\t"
+            "ds_read_b64 %8, %17 offset:32\n\tds_read_b64 %9, %17 offset:40\n\tds_read_b64 %10, %20 offset:32\n\tds_read_b64 %11, %20 offset:40\n\t"
+            "ds_read_b64 %12, %18 offset:64\n\tds_read_b64 %13, %18 offset:72\n\tds_read_b64 %14, %21 offset:64\n\tds_read_b64 %15, %21 offset:72\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(b.s1[0][0]), "=&v"(b.s1[0][1]), "=&v"(b.s2[0][0]), "=&v"(b.s2[0][1]), "=&v"(b.s1[1][0]), "=&v"(b.s1[1][1]),
+              "=&v"(b.s2[1][0]), "=&v"(b.s2[1][1]), "=&v"(b.s1[2][0]), "=&v"(b.s1[2][1]), "=&v"(b.s2[2][0]), "=&v"(b.s2[2][1]),
+              "=&v"(b.s1[3][0]), "=&v"(b.s1[3][1]), "=&v"(b.s2[3][0]), "=&v"(b.s2[3][1])
+            : "v"(a0), "v"(a1), "v"(a2), "v"(c0), "v"(c1), "v"(c2)
+            : "memory");
     }
-#undef STG_CV_G
-}
-__device__ __forceinline__ void wait_half(BHalf &b) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(b.s1[0][0]), "+v"(b.s1[0][1]), "+v"(b.s2[0][0]), "+v"(b.s2[0][1]), "+v"(b.s1[1][0]),
-                   "+v"(b.s1[1][1]), "+v"(b.s2[1][0]), "+v"(b.s2[1][1]), "+v"(b.s1[2][0]), "+v"(b.s1[2][1]),
-                   "+v"(b.s2[2][0]), "+v"(b.s2[2][1]), "+v"(b.s1[3][0]), "+v"(b.s1[3][1]), "+v"(b.s2[3][0]),
-                   "+v"(b.s2[3][1])
-                 :
-                 : "memory");
-}
-// the same with a counted wait per group: LDS returns in order, so with 4 (3 - i) younger reads outstanding group i has
-// landed and its three MFMAs issue while the later groups are still in flight (call right after load_b_half)
-template <int CNT>
-__device__ __forceinline__ void wait_group(u32x2 &a0, u32x2 &a1, u32x2 &a2, u32x2 &a3) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "n"(CNT) : "memory");
-}
-template <int H>
-__device__ __forceinline__ void mma_half_counted(const u32x4 (&w)[kWpVecs], BHalf &b, f32x4 &acc) {
-#define STG_CV_W(i, cnt)                                                                  \
-    wait_group<cnt>(b.s1[i][0], b.s1[i][1], b.s2[i][0], b.s2[i][1]);                      \
-    acc = mma(w[3 * (4 * H + i) + 0], b.s1[i][0], b.s1[i][1], acc);                       \
-    acc = mma(w[3 * (4 * H + i) + 1], b.s1[i][0], b.s1[i][1], acc);                       \
-    acc = mma(w[3 * (4 * H + i) + 2], b.s2[i][0], b.s2[i][1], acc);
-    STG_CV_W(0, 12)
-    STG_CV_W(1, 8)
-    STG_CV_W(2, 4)
-    STG_CV_W(3, 0)
-#undef STG_CV_W
 }
 template <int H>
 __device__ __forceinline__ void mma_half(const u32x4 (&w)[kWpVecs], const BHalf &b, f32x4 &acc) {

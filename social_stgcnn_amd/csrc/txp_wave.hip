@@ -521,9 +521,9 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
                 cv::BHalf b;
                 f32x4 z = binit;
                 cv::load_b_half<0>(lds_base, tl, b);
-                cv::mma_half_counted<0>(w, b, z);
+                cv::mma_half<0>(w, b, z);
                 cv::load_b_half<1>(lds_base, tl, b);
-                cv::mma_half_counted<1>(w, b, z);
+                cv::mma_half<1>(w, b, z);
                 if (tl.ok && kq < 3) {
                     if (is_out) {
                         // v.view(N, C, P, V) (model.py:195): the (P, C, V) conv output IS the (C, P, V) tensor
@@ -1195,15 +1195,14 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
             for (int t = 0; t < kX6Tiles; ++t) {
                 if (t < ntiles) {
                     const cv::Tile tl = cv::tile_of<1>(t, ptab, npos, lg, vi);
-                    // two half-tiles through ONE 32-register operand set (96 weight + 40 gradient registers are live):
-                    // the second half's reads wait for the first half's MFMAs to be issued, the SIMD's other wave
-                    // covers the latency
+                    // two half-tiles through ONE 32-register operand set (96 weight + 40 gradient registers are live);
+                    // each half's reads and their wait are one asm statement, the SIMD's other wave covers the latency
                     cv::BHalf b;
                     f32x4 acc = keep ? dcur[t] : zero;
                     cv::load_b_half<0>(lds_base, tl, b);
-                    cv::mma_half_counted<0>(w, b, acc);
+                    cv::mma_half<0>(w, b, acc);
                     cv::load_b_half<1>(lds_base, tl, b);
-                    cv::mma_half_counted<1>(w, b, acc);
+                    cv::mma_half<1>(w, b, acc);
                     dcur[t] = acc;
                 }
             }

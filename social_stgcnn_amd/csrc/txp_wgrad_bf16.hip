@@ -49,30 +49,26 @@ struct Item {
     const float *pl, *dz;
 };
 
-__device__ __forceinline__ u32x2 tr_read(unsigned addr, int imm_sel) {
-    u32x2 r;
-    // (offset immediates: the three pieces of a record)
-    if (imm_sel == 0) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-    else if (imm_sel == 1) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:32" : "=v"(r) : "v"(addr) : "memory");
-    else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:64" : "=v"(r) : "v"(addr) : "memory");
-    return r;
-}
-
 struct Op3 {            // one operand chunk (8 positions of the lane's channel), three pieces
     u32x2 h[2], m[2], l[2];
 };
+// The transposing reads of an operand AND their s_waitcnt are ONE asm statement: the compiler never sees a register
+// whose data is still in flight (a copy inserted between a read and a separate wait statement would pick up stale
+// data).  The other waves of the SIMD cover the LDS latency.  (offset immediates: the three pieces of a record)
 __device__ __forceinline__ void read_op(unsigned a0, unsigned a1, Op3 &o) {
-    o.h[0] = tr_read(a0, 0);
-    o.h[1] = tr_read(a1, 0);
-    o.m[0] = tr_read(a0, 1);
-    o.m[1] = tr_read(a1, 1);
-    o.l[0] = tr_read(a0, 2);
-    o.l[1] = tr_read(a1, 2);
+    asm volatile("ds_read_b64_tr_b16 %0, %6\n\tds_read_b64_tr_b16 %1, %7\n\t"
+                 "ds_read_b64_tr_b16 %2, %6 offset:32\n\tds_read_b64_tr_b16 %3, %7 offset:32\n\t"
+                 "ds_read_b64_tr_b16 %4, %6 offset:64\n\tds_read_b64_tr_b16 %5, %7 offset:64\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o.h[0]), "=&v"(o.h[1]), "=&v"(o.m[0]), "=&v"(o.m[1]), "=&v"(o.l[0]), "=&v"(o.l[1])
+                 : "v"(a0), "v"(a1)
+                 : "memory");
 }
-__device__ __forceinline__ void wait_op(Op3 &o) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(o.h[0]), "+v"(o.h[1]), "+v"(o.m[0]), "+v"(o.m[1]), "+v"(o.l[0]), "+v"(o.l[1])
-                 :
+// bf16 storage: the h piece only
+__device__ __forceinline__ void read_op_h(unsigned a0, unsigned a1, Op3 &o) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o.h[0]), "=&v"(o.h[1])
+                 : "v"(a0), "v"(a1)
                  : "memory");
 }
 __device__ __forceinline__ f32x4 mma(const u32x2 (&a)[2], const u32x2 (&b)[2], const f32x4 &c) {
@@ -210,16 +206,13 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
         Op3 dzo, ao;
         if (BF) {
             // bf16 storage: one piece, one product per tap
-            dzo.h[0] = tr_read(za[0], 0);
-            dzo.h[1] = tr_read(za[1], 0);
+            read_op_h(za[0], za[1], dzo);
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 if (k < ntap) {
                     const int tap = hf * 5 + k;
                     const int shift = ((tap / 3 - 1) * SWa + (tap % 3 - 1)) * kRec;
-                    ao.h[0] = tr_read(aa[0] + shift, 0);
-                    ao.h[1] = tr_read(aa[1] + shift, 0);
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ao.h[0]), "+v"(ao.h[1]), "+v"(dzo.h[0]), "+v"(dzo.h[1])::"memory");
+                    read_op_h(aa[0] + shift, aa[1] + shift, ao);
                     acc[k] = mma(dzo.h, ao.h, acc[k]);
                 } else {
                     const u32x2 one[2] = {u32x2{0x3f803f80u, 0x3f803f80u}, u32x2{0x3f803f80u, 0x3f803f80u}};
@@ -235,11 +228,6 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
                 const int tap = hf * 5 + k;
                 const int shift = ((tap / 3 - 1) * SWa + (tap % 3 - 1)) * kRec;
                 read_op(aa[0] + shift, aa[1] + shift, ao);
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(ao.h[0]), "+v"(ao.h[1]), "+v"(ao.m[0]), "+v"(ao.m[1]), "+v"(ao.l[0]), "+v"(ao.l[1]),
-                               "+v"(dzo.h[0]), "+v"(dzo.h[1]), "+v"(dzo.m[0]), "+v"(dzo.m[1]), "+v"(dzo.l[0]), "+v"(dzo.l[1])
-                             :
-                             : "memory");
                 acc[k] = mma(dzo.h, ao.h, acc[k]);
                 acc[k] = mma(dzo.m, ao.h, acc[k]);
                 acc[k] = mma(dzo.h, ao.m, acc[k]);
