@@ -44,7 +44,7 @@ template <bool BF> struct StageType { typedef f32x4 type; };
 template <> struct StageType<true> { typedef unsigned type __attribute__((ext_vector_type(2))); };
 
 struct Item {
-    int vi;
+    int vi, w0, vc;        // pedestrians of the scene; first column and width of the chunk (vc == vi: the whole scene)
     bool valid;
     const float *pl, *dz;
 };
@@ -88,9 +88,10 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     const int ks = wave >> 1, hf = wave & 1;                    // K-step and tap half of this wave
     const int kg = lane >> 4, rq = (lane & 15) >> 2, cp = lane & 3;   // operand chunk, row and column quad of the tr reads
     const int nq = lane & 15, kq = lane >> 4;                   // accumulator: column (input channel), row quad
-    const int img = image_bytes(V, BF);
+    const int Vc = wgrad_image_v(V);                   // widest work item: a scene, or a <= 32-column chunk of a larger one
+    const int img = image_bytes(Vc, BF);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)sm;
-    const int items = a.N;
+    const int nch = wgrad_chunks(V), items = a.N * nch;
     const int64_t plane_off = ws_plane_off(L, V, layer), dzs_floats = dz_slot(V);
 
     f32x4 acc[5];
@@ -102,19 +103,25 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
         Raw w{-1, 0, 0};
         w.at = walk_item(r, wg, nwg, items, order != nullptr && a.serpentine);
         if (w.at >= 0) {
-            w.n = order ? order[w.at] : w.at;
-            w.v = order ? order_peds[w.at] : (num_peds ? num_peds[w.at] : V);
+            const int si = nch > 1 ? w.at / nch : w.at;
+            w.n = order ? order[si] : si;
+            w.v = order ? order_peds[si] : (num_peds ? num_peds[si] : V);
         }
         return w;
     };
     auto finish = [&](const Raw &w) -> Item {
-        Item it{0, false, nullptr, nullptr};
+        Item it{0, 0, 0, false, nullptr, nullptr};
         if (w.at < 0) return it;
+        const int chunk = nch > 1 ? w.at - (w.at / nch) * nch : 0;
         const int vfull = w.v < 0 ? 0 : (w.v > V ? V : w.v);
-        if (vfull == 0) return it;
+        const int nc = wgrad_chunks(vfull);            // a scene of more than 32 pedestrians is cut into equal column chunks
+        if (vfull == 0 || chunk >= nc) return it;
+        const int wc = nc > 1 ? (vfull + nc - 1) / nc : vfull;
         it.pl = a.ws + w.n * a.ws_stride + plane_off;
         it.dz = a.dzg + ((int64_t)w.n * (L.L + 1) + layer) * dzs_floats;
         it.vi = vfull;
+        it.w0 = chunk * wc;
+        it.vc = (vfull - it.w0) < wc ? (vfull - it.w0) : wc;
         it.valid = true;
         return it;
     };
@@ -133,12 +140,24 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     struct Stage { StageV v[2]; };
     auto load = [&](const Item &it, Stage &s) {
         const bool live = it.valid && !STG_SKIP(a, 64);
-        const int na = live ? C * save_sw(it.vi, BF) * 3 : 0, nz = live ? C * save_vw(it.vi, BF) * 3 : 0;
+        const bool whole = it.vc == it.vi;
+        // image rows: the whole scene's saved rows as they are, or the chunk's vc + 2 plane columns / vc dz columns
+        const int SWi = whole ? save_sw(it.vi, BF) : it.vc + 2, VWi = whole ? save_vw(it.vi, BF) : it.vc;
+        const int SWf = save_sw(it.vi, BF), VWf = save_vw(it.vi, BF);
+        const int na = live ? C * SWi * 3 : 0, nz = live ? C * VWi * 3 : 0;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + u * kWavesB * 64;
             constexpr int TF = BF ? 2 : 4;             // floats per task
-            const float *src = e < na ? it.pl + TF * e : (e < na + nz ? it.dz + TF * (e - na) : a.ws);
+            int ea = e, ez = e - na;                   // quad index in the saved plane / dz array
+            if (!whole) {
+                // chunk: (row, column, quad) of the image -> the scene's saved row, shifted by the chunk's first column
+                const int ra = e / 3, qa = e - ra * 3, ha = ra / SWi, ca = ra - ha * SWi;
+                ea = (ha * SWf + it.w0 + ca) * 3 + qa;
+                const int rz = ez / 3, qz = ez - rz * 3, hz = rz / (VWi > 0 ? VWi : 1), cz = rz - hz * VWi;
+                ez = (hz * VWf + it.w0 + cz) * 3 + qz;
+            }
+            const float *src = e < na ? it.pl + TF * ea : (e < na + nz ? it.dz + TF * ez : a.ws);
             if constexpr (BF) asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(s.v[u]) : "v"(src) : "memory");
             else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(s.v[u]) : "v"(src) : "memory");
         }
@@ -147,8 +166,10 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     auto landed = [&](Stage &s) { asm volatile("s_waitcnt vmcnt(2)" : "+v"(s.v[0]), "+v"(s.v[1])::"memory"); };
     auto convert = [&](const Item &it, const Stage &s, unsigned char *buf) {
         if (!it.valid || STG_SKIP(a, 64)) return;
-        const int SWa = save_sw(it.vi, BF), VWz = save_vw(it.vi, BF), na = C * SWa * 3, nz = C * VWz * 3;
-        unsigned char *dzimg = buf + image_a_recs(V, BF) * kRec;
+        const bool whole = it.vc == it.vi;
+        const int SWa = whole ? save_sw(it.vi, BF) : it.vc + 2, VWz = whole ? save_vw(it.vi, BF) : it.vc;
+        const int na = C * SWa * 3, nz = C * VWz * 3;
+        unsigned char *dzimg = buf + image_a_recs(Vc, BF) * kRec;
         // zero border rows of the plane image (rows 0 and C + 1) and the zero record behind dz: 8-byte stores
         constexpr int U = kRec / 8;
         for (int e = tid; e < 2 * SWa * U + U; e += kWavesB * 64) {
@@ -181,12 +202,14 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     // ---- this wave's K-step of the scene staged in `buf` ------------------------------------------------------------
     auto compute = [&](const Item &it, unsigned buf_off) {
         if (!it.valid || STG_SKIP(a, 128)) return;
-        const int vi = it.vi, npos = C * vi, SWa = save_sw(vi, BF), VWz = save_vw(vi, BF);
+        const bool whole = it.vc == it.vi;
+        const int vi = it.vc, npos = C * vi;           // (the K loop of a chunk is that of a scene of vc pedestrians)
+        const int SWa = whole ? save_sw(vi, BF) : vi + 2, VWz = whole ? save_vw(vi, BF) : vi;
         if (32 * ks >= npos) return;
         unsigned inv = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)vi));
         while (inv * (unsigned)vi < 65536u) ++inv;
         while ((inv - 1u) * (unsigned)vi >= 65536u) --inv;
-        const unsigned abase = lds0 + buf_off, zbase = abase + image_a_recs(V, BF) * kRec;
+        const unsigned abase = lds0 + buf_off, zbase = abase + image_a_recs(Vc, BF) * kRec;
         unsigned za[2], aa[2];
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
@@ -320,15 +343,16 @@ __global__ __launch_bounds__(kWavesB * 64, 6) void txp_wgrad_bf16_kernel(const W
 
 }  // namespace
 
-// whole-scene work items only (V <= kWgradChunkV): larger scenes (column chunks) run txp_wgrad.hip
+// every V: a scene of more than kWgradChunkV pedestrians is cut into equal column chunks (as in txp_wgrad.hip)
 bool wgrad_bf16_fits(const ModelLayout &L, int V) {
     const bool bf = (L.flags & STG_OPT_BF16_STORE) != 0;
-    return V <= kWgradChunkV && !(L.flags & STG_OPT_F32_MFMA) && 2 * (size_t)image_bytes(V, bf) * 2 <= (size_t)kLdsBytes;
+    (void)V;
+    return !(L.flags & STG_OPT_F32_MFMA) && 2 * (size_t)image_bytes(kWgradChunkV, bf) * 2 <= (size_t)kLdsBytes;
 }
 
 void wgrad_bf16_geom(WgradGeom *g, const ModelLayout &L, int V) {
     const size_t row = (size_t)((Cfg::P * Cfg::P * 9 + Cfg::P + 3) & ~3) * sizeof(float) * kWavesB;
-    size_t lds = 2 * (size_t)image_bytes(V, (L.flags & STG_OPT_BF16_STORE) != 0);
+    size_t lds = 2 * (size_t)image_bytes(wgrad_image_v(V), (L.flags & STG_OPT_BF16_STORE) != 0);
     if (lds < row) lds = row;
     g->waves = kWavesB;
     g->nbuf = 2;
