@@ -784,7 +784,9 @@ def test_every_crowd_size_of_the_wave_path(dev):
     assert max(worst.values()) < 1e-4
 
 
-def test_bf16_storage_mode_measured_error(dev, monkeypatch):
+@pytest.mark.parametrize("counts", ([57, 2, 33, 17, 8, 32, 5, 40], [32, 2, 31, 17, 8, 32, 5, 24]),
+                         ids=("crowds_to_57_fp32_mfma_chains", "crowds_to_32_bf16_pipe_kernels"))
+def test_bf16_storage_mode_measured_error(dev, monkeypatch, counts):
     """BASELINE configs[2]: STG_OPT_BF16_STORE keeps the saved TXP planes a_l, the pre-activations z_l and the dz_l
     hand-off in bf16 (fp32 compute, accumulation, parameters, inputs).  What that costs, measured against the fp32
     oracle on a ragged batch (2..57 pedestrians): V_pred and the loss are UNCHANGED (the forward computes from its
@@ -795,7 +797,6 @@ def test_bf16_storage_mode_measured_error(dev, monkeypatch):
     from social_stgcnn_amd.metrics import bivariate_loss
     O = _oracle()
     monkeypatch.setitem(ops.OPTIONS, "bf16_store", True)
-    counts = [57, 2, 33, 17, 8, 32, 5, 40]
     vmax = max(counts)
     rels = [_synthetic_scene(vmax, 300 + i) for i in range(len(counts))]
     for r, c in zip(rels, counts):
