@@ -499,6 +499,7 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
     __builtin_amdgcn_wave_barrier();
 
     // ---- TXP-CNN (model.py:187-195) -------------------------------------------------------------------
+    if (STG_SKIP(a, 16)) return;                       // (diagnostic build: time the block alone)
     const unsigned lds_base = (unsigned)(uintptr_t)img;
     f32x4 av[kF6Tiles];
 #pragma unroll
