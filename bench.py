@@ -187,9 +187,9 @@ def issued_bf16_flop(kernel, v):
     if v > 32:
         return None
     if kernel.startswith("txp_fwd_x6") or kernel.startswith("txp_bwd_x6"):
-        return 6 * ((5 * v + 15) // 16) * 24 * 16384          # six convs, 24 MFMAs per 16-position tile
+        return 5 * ((5 * v + 15) // 16) * 24 * 16384          # five convs (n_txpcnn = 5: tpcnns.4 is dead), 24 MFMAs per tile
     if kernel.startswith("txp_wgrad_bf16"):
-        return 6 * ((5 * v + 31) // 32) * 57 * 16384          # six layers, 9 taps x 6 products + 3 bias MFMAs per 32 positions
+        return 5 * ((5 * v + 31) // 32) * 57 * 16384          # five layers, 9 taps x 6 products + 3 bias MFMAs per 32 positions
     return None
 
 

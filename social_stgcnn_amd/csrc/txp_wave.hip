@@ -435,7 +435,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
 }
 
 // ------------------------------------------------------------------------------------------
-// forward, exact-bf16 variant (x6): the six convs on v_mfma_f32_16x16x32_bf16 with three-piece operands
+// forward, exact-bf16 variant (x6 = six bf16 products per fp32 product): the convs on v_mfma_f32_16x16x32_bf16
 // ------------------------------------------------------------------------------------------
 // txp_conv_bf16.hpp.  a_l lives in LDS as three position-major bf16 piece images (7 row slots: no in-place ring is
 // needed, because the layer's outputs stay in REGISTERS until every tile has read its inputs); the same registers are

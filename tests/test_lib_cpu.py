@@ -36,6 +36,13 @@ def test_layout_queries_match_reference_counts(L):
     assert L.stg_model_buffer_count(ctypes.byref(d)) == 30           # 3 BatchNorm x (mean, var) x 5
     assert L.stg_model_stat_floats(ctypes.byref(d)) == 30
     assert L.stg_model_ws_floats(ctypes.byref(d), 32) == 64 + 32 * (16 + 8 + 40 + 40 + 40 + 4 * 60) + 5 * 12 * 240
+    # batch tail of the workspace: the prepared bf16 A operands of the five input-gradient convs (24 x 64 lanes x 16 bytes
+    # each) when the exact-bf16 backward serves the batch (V <= 32), nothing otherwise
+    assert L.stg_model_ws_tail_floats(ctypes.byref(d), 32) == 5 * 24 * 64 * 4
+    assert L.stg_model_ws_tail_floats(ctypes.byref(d), 64) == 0
+    d_f32 = ops.make_desc(1, 5, 2, 5, 8, 12, 3, 2, False, True)
+    d_f32.flags |= _lib.OPT_F32_MFMA
+    assert L.stg_model_ws_tail_floats(ctypes.byref(d_f32), 32) == 0
     d2 = ops.make_desc(2, 3, 2, 5, 8, 12, 3, 2, False, False)
     # second block: identity residual -> no residual conv / BN parameters
     blk0 = 10 + 5 + 10 + 1 + 75 + 5 + 10 + 10 + 5 + 10 + 1
