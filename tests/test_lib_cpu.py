@@ -41,7 +41,8 @@ def test_layout_queries_match_reference_counts(L):
     assert L.stg_model_ws_tail_floats(ctypes.byref(d), 32) == 5 * 24 * 64 * 4
     assert L.stg_model_ws_tail_floats(ctypes.byref(d), 64) == 0
     d_f32 = ops.make_desc(1, 5, 2, 5, 8, 12, 3, 2, False, True)
-    d_f32.flags |= _lib.OPT_F32_MFMA
+    from social_stgcnn_amd import _lib as lib_mod
+    d_f32.flags |= lib_mod.OPT_F32_MFMA
     assert L.stg_model_ws_tail_floats(ctypes.byref(d_f32), 32) == 0
     d2 = ops.make_desc(2, 3, 2, 5, 8, 12, 3, 2, False, False)
     # second block: identity residual -> no residual conv / BN parameters
