@@ -707,6 +707,256 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
 }
 
 // ------------------------------------------------------------------------------------------
+// backward, column mode (wave-per-scene kernels, vi <= 64, first-block shape, no input gradient): lane = pedestrian, the
+// 8 time steps of every array in registers -- the mirror of stgcn_block_fwd_cols.  Nothing of the block lives in LDS
+// except ds ([C][T][vi] in `D`, read once); the saved arrays g, h2, ax, colsum and the block input come straight from
+// HBM (all ~130 loads of a lane in flight at once); cross-lane traffic: the DPP wave sums of the 142 parameter
+// gradients and BatchNorm reductions, in five batches.  Gradients leave as the scene's own row (`row[b.* + k]`, every
+// entry written exactly once, by lane 0).
+// ------------------------------------------------------------------------------------------
+template <typename Args>
+__device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float *P_, const BlockLayout &b, int n, int vi,
+                                                     const float *D, float *row, const float *wsn) {
+    constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, CIN = Cfg::CIN0;
+    const int w = threadIdx.x & 63, V = a.V;
+    const bool act = w < vi, lane0 = w == 0;
+    const bool train = a.lay.bn_mode == 1, res2 = b.residual == 2;
+    const float inv_cnt = 1.0f / (float)(T * vi);
+    const float *wsa = wsn + a.lay.ws_hdr_floats;
+    const float *w_ax = wsa + (int64_t)b.ws_ax * V, *w_cs = wsa + (int64_t)b.ws_cs * V;
+    const float *w_g = wsa + (int64_t)b.ws_g * V, *w_h2 = wsa + (int64_t)b.ws_h2 * V;
+    const float *hdr = wsn + b.ws_hdr;
+    float m1[C], r1[C], m2[C], r2[C], mr[C], rr[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        m1[c] = hdr[c]; r1[c] = hdr[C + c]; m2[c] = hdr[2 * C + c];
+        r2[c] = hdr[3 * C + c]; mr[c] = hdr[4 * C + c]; rr[c] = hdr[5 * C + c];
+    }
+    // ---- loads: everything this pedestrian needs, in flight together ------------------------------------------------
+    float ds[C][T], h2[C][T], g[C][T], ax[CIN][T], cs[T], x[CIN][T];
+    {
+        const float *xn = a.x + n * a.x_sn + w * a.x_sv;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            cs[t] = act ? w_cs[t * vi + w] : 0.f;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                ax[ci][t] = act ? w_ax[(ci * T + t) * vi + w] : 0.f;
+                x[ci][t] = (act && b.residual != 0) ? xn[ci * a.x_sc + t * a.x_st] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int i = (c * T + t) * vi + w;
+                h2[c][t] = act ? w_h2[i] : 0.f;
+                g[c][t] = act ? w_g[i] : 0.f;
+                ds[c][t] = act ? D[i] : 0.f;
+            }
+        }
+    }
+    // ---- B1: du = ds * prelu'(u); BatchNorm tcn.3 / residual.1 reductions ------------------------------------------------
+    const float ao = P_[b.prelu_o], a1 = P_[b.prelu1];
+    float s1[3 * C + 1];
+#pragma unroll
+    for (int k = 0; k < 3 * C + 1; ++k) s1[k] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float g2 = P_[b.bn2_g + c], b2 = P_[b.bn2_b + c];
+        const float gr = res2 ? P_[b.bnr_g + c] : 0.f, br = res2 ? P_[b.bnr_b + c] : 0.f, rb = res2 ? P_[b.res_b + c] : 0.f;
+        float rw[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) rw[ci] = res2 ? P_[b.res_w + c * CIN + ci] : 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float x2 = (h2[c][t] - m2[c]) * r2[c];
+            float u = fmaf(x2, g2, b2), xr = 0.f;
+            if (res2) {
+                float r = rb;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) r = fmaf(rw[ci], x[ci][t], r);
+                xr = (r - mr[c]) * rr[c];
+                u += fmaf(xr, gr, br);
+            }
+            const float d = ds[c][t];
+            float du = d;
+            if (!a.lay.use_mdn && !(u > 0.f)) {
+                du = ao * d;
+                s1[3 * C] = fmaf(d, u, s1[3 * C]);
+            }
+            ds[c][t] = du;                             // (ds now holds du)
+            h2[c][t] = x2;                             // (h2 now holds xhat2)
+            s1[c] += du;
+            s1[C + c] = fmaf(du, x2, s1[C + c]);
+            s1[2 * C + c] = fmaf(du, xr, s1[2 * C + c]);
+        }
+    }
+    wave_sum_n<3 * C + 1>(s1);
+    if (lane0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            row[b.bn2_b + c] = s1[c];
+            row[b.bn2_g + c] = s1[C + c];
+            if (res2) {
+                row[b.bnr_b + c] = s1[c];
+                row[b.bnr_g + c] = s1[2 * C + c];
+            }
+        }
+        row[b.prelu_o] = s1[3 * C];
+    }
+    // ---- B2: dh2, dr; residual 1x1 conv gradients --------------------------------------------------------------------
+    {
+        float s2[C * CIN + C];
+#pragma unroll
+        for (int k = 0; k < C * CIN + C; ++k) s2[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float mdu = train ? s1[c] * inv_cnt : 0.f, mdx2 = train ? s1[C + c] * inv_cnt : 0.f;
+            const float mdxr = train ? s1[2 * C + c] * inv_cnt : 0.f;
+            const float k2 = P_[b.bn2_g + c] * r2[c];
+            const float gr = res2 ? P_[b.bnr_g + c] : 0.f, rb = res2 ? P_[b.res_b + c] : 0.f;
+            float rw[CIN];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) rw[ci] = res2 ? P_[b.res_w + c * CIN + ci] : 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float du = ds[c][t];
+                if (res2) {
+                    float r = rb;
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) r = fmaf(rw[ci], x[ci][t], r);
+                    const float xr = (r - mr[c]) * rr[c];
+                    const float dr = act ? gr * rr[c] * (du - mdu - xr * mdxr) : 0.f;
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) s2[c * CIN + ci] = fmaf(dr, x[ci][t], s2[c * CIN + ci]);
+                    s2[C * CIN + c] += dr;
+                }
+                h2[c][t] = act ? k2 * (du - mdu - h2[c][t] * mdx2) : 0.f;      // (h2 now holds dh2)
+            }
+        }
+        if (res2) {
+            wave_sum_n<C * CIN + C>(s2);
+            if (lane0) {
+#pragma unroll
+                for (int k = 0; k < C * CIN; ++k) row[b.res_w + k] = s2[k];
+#pragma unroll
+                for (int c = 0; c < C; ++c) row[b.res_b + c] = s2[C * CIN + c];
+            }
+        }
+    }
+    // ---- B3a: h1 = prelu(bn1(g)) (into the ds registers); temporal conv weight gradients, one tap at a time -------------
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float g1 = P_[b.bn1_g + c], b1p = P_[b.bn1_b + c];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float b1 = fmaf((g[c][t] - m1[c]) * r1[c], g1, b1p);
+            ds[c][t] = b1 > 0.f ? b1 : a1 * b1;
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < KT; ++dt) {
+        float sw[C * C];
+#pragma unroll
+        for (int k = 0; k < C * C; ++k) sw[k] = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int th = t + dt - 1;                 // h1 time step of this tap (zero-padded outside 0..T-1)
+            if (th >= 0 && th < T) {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int ci = 0; ci < C; ++ci) sw[c * C + ci] = fmaf(h2[c][t], ds[ci][th], sw[c * C + ci]);
+            }
+        }
+        wave_sum_n<C * C>(sw);
+        if (lane0) {
+#pragma unroll
+            for (int k = 0; k < C * C; ++k) row[b.tcn_w + k * KT + dt] = sw[k];
+        }
+    }
+    // ---- B3b: dh1 -> db1, conv bias gradient, BatchNorm tcn.0 reductions, PReLU slope -------------------------------------
+    float s3[3 * C + 1];
+#pragma unroll
+    for (int k = 0; k < 3 * C + 1; ++k) s3[k] = 0.f;
+    {
+        float dh1[C][T];
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+            for (int t = 0; t < T; ++t) dh1[ci][t] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) s3[c] += h2[c][t];
+#pragma unroll
+            for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+                for (int dt = 0; dt < KT; ++dt) {
+                    const float wv = P_[b.tcn_w + (c * C + ci) * KT + dt];
+                    // dh1[ci][t] += W[c][ci][dt] dh2[c][t - dt + 1]
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const int to = t - dt + 1;
+                        if (to >= 0 && to < T) dh1[ci][t] = fmaf(wv, h2[c][to], dh1[ci][t]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float g1 = P_[b.bn1_g + c], b1p = P_[b.bn1_b + c];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float x1 = (g[c][t] - m1[c]) * r1[c];
+                const float b1 = fmaf(x1, g1, b1p);
+                float db = dh1[c][t];
+                if (!(b1 > 0.f)) {
+                    db = a1 * dh1[c][t];
+                    s3[3 * C] = fmaf(dh1[c][t], b1, s3[3 * C]);
+                }
+                ds[c][t] = db;                         // (ds now holds db1)
+                g[c][t] = x1;                          // (g now holds xhat1)
+                s3[C + c] += db;
+                s3[2 * C + c] = fmaf(db, x1, s3[2 * C + c]);
+            }
+        }
+    }
+    wave_sum_n<3 * C + 1>(s3);
+    if (lane0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            row[b.tcn_b + c] = s3[c];
+            row[b.bn1_b + c] = s3[C + c];
+            row[b.bn1_g + c] = s3[2 * C + c];
+        }
+        row[b.prelu1] = s3[3 * C];
+    }
+    // ---- B4: dg; gcn 1x1 conv gradients ------------------------------------------------------------------------------
+    {
+        float s4[C * CIN + C];
+#pragma unroll
+        for (int k = 0; k < C * CIN + C; ++k) s4[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float mdb = train ? s3[C + c] * inv_cnt : 0.f, mdbx = train ? s3[2 * C + c] * inv_cnt : 0.f;
+            const float k1 = P_[b.bn1_g + c] * r1[c];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float dg = act ? k1 * (ds[c][t] - mdb - g[c][t] * mdbx) : 0.f;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) s4[c * CIN + ci] = fmaf(dg, ax[ci][t], s4[c * CIN + ci]);
+                s4[C * CIN + c] = fmaf(dg, cs[t], s4[C * CIN + c]);
+            }
+        }
+        wave_sum_n<C * CIN + C>(s4);
+        if (lane0) {
+#pragma unroll
+            for (int k = 0; k < C * CIN; ++k) row[b.gcn_w + k] = s4[k];
+#pragma unroll
+            for (int c = 0; c < C; ++c) row[b.gcn_b + c] = s4[C * CIN + c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward.  ds (gradient w.r.t. the block output, [C][T][vi]) is in `D` (LDS) and is consumed in place.  If `dxs`
 // != nullptr the gradient w.r.t. the block input is written there ([CIN][T][vi], LDS; may alias D) -- needed for
 // stacked blocks; `dxg` is the optional global dx.  Small-parameter gradients go to `gsm`: ACCUM = true adds (an

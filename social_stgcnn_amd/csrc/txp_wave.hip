@@ -622,6 +622,11 @@ __device__ __forceinline__ void txp_bwd_block_tail(const TxpBwdArgs &a, const fl
         }
     __builtin_amdgcn_wave_barrier();
     float *row = slope_row - L.n_blk_params;
+    if (vi <= 64 && !STG_SKIP(a, 8192)) {
+        // column mode: lane = pedestrian, all 8 time steps in registers (the mirror of the forward's column mode)
+        stgcn_block_bwd_cols(a, blk_params, L.blk[0], n, vi, D, row, a.ws + n * a.ws_stride);
+        return;
+    }
     stgcn_block_bwd<Cfg::CIN0, 0, false>(a, blk_params, L.blk[0], n, vi, D, H1, DH2, D, nullptr, tot, row,
                                          a.ws + n * a.ws_stride, nullptr, nullptr, nullptr, nullptr, ptab);
 }
