@@ -714,12 +714,17 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
 // gradients and BatchNorm reductions, in five batches.  Gradients leave as the scene's own row (`row[b.* + k]`, every
 // entry written exactly once, by lane 0).
 // ------------------------------------------------------------------------------------------
-template <typename Args>
+// HALF (vi <= 32): lane = (pedestrian, time half) -- lanes 0..31 own t = 0..3, lanes 32..63 t = 4..7 -- so that a crowd of
+// <= 32 uses every lane and the per-lane arrays halve; the temporal conv's two taps across the half boundary come from
+// the partner lane (lane ^ 32).
+template <bool HALF, typename Args>
 __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float *P_, const BlockLayout &b, int n, int vi,
                                                      const float *D, float *row, const float *wsn) {
     constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, CIN = Cfg::CIN0;
-    const int w = threadIdx.x & 63, V = a.V;
-    const bool act = w < vi, lane0 = w == 0;
+    constexpr int TL = HALF ? T / 2 : T;               // time steps of a lane
+    const int lane = threadIdx.x & 63, V = a.V;
+    const int w = HALF ? lane & 31 : lane, hh = HALF ? lane >> 5 : 0, toff = TL * hh;
+    const bool act = w < vi, lane0 = lane == 0;
     const bool train = a.lay.bn_mode == 1, res2 = b.residual == 2;
     const float inv_cnt = 1.0f / (float)(T * vi);
     const float *wsa = wsn + a.lay.ws_hdr_floats;
@@ -733,20 +738,21 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
         r2[c] = hdr[3 * C + c]; mr[c] = hdr[4 * C + c]; rr[c] = hdr[5 * C + c];
     }
     // ---- loads: everything this pedestrian needs, in flight together ------------------------------------------------
-    float ds[C][T], h2[C][T], g[C][T], ax[CIN][T], cs[T], x[CIN][T];
+    float ds[C][TL], h2[C][TL], g[C][TL], ax[CIN][TL], cs[TL], x[CIN][TL];
     {
         const float *xn = a.x + n * a.x_sn + w * a.x_sv;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            cs[t] = act ? w_cs[t * vi + w] : 0.f;
+        for (int t = 0; t < TL; ++t) {
+            const int tg = toff + t;                   // the lane's time step t is step tg of the scene
+            cs[t] = act ? w_cs[tg * vi + w] : 0.f;
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) {
-                ax[ci][t] = act ? w_ax[(ci * T + t) * vi + w] : 0.f;
-                x[ci][t] = (act && b.residual != 0) ? xn[ci * a.x_sc + t * a.x_st] : 0.f;
+                ax[ci][t] = act ? w_ax[(ci * T + tg) * vi + w] : 0.f;
+                x[ci][t] = (act && b.residual != 0) ? xn[ci * a.x_sc + tg * a.x_st] : 0.f;
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const int i = (c * T + t) * vi + w;
+                const int i = (c * T + tg) * vi + w;
                 h2[c][t] = act ? w_h2[i] : 0.f;
                 g[c][t] = act ? w_g[i] : 0.f;
                 ds[c][t] = act ? D[i] : 0.f;
@@ -766,7 +772,7 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci) rw[ci] = res2 ? P_[b.res_w + c * CIN + ci] : 0.f;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
+        for (int t = 0; t < TL; ++t) {
             const float x2 = (h2[c][t] - m2[c]) * r2[c];
             float u = fmaf(x2, g2, b2), xr = 0.f;
             if (res2) {
@@ -817,7 +823,7 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) rw[ci] = res2 ? P_[b.res_w + c * CIN + ci] : 0.f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < TL; ++t) {
                 const float du = ds[c][t];
                 if (res2) {
                     float r = rb;
@@ -847,10 +853,25 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
     for (int c = 0; c < C; ++c) {
         const float g1 = P_[b.bn1_g + c], b1p = P_[b.bn1_b + c];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
+        for (int t = 0; t < TL; ++t) {
             const float b1 = fmaf((g[c][t] - m1[c]) * r1[c], g1, b1p);
             ds[c][t] = b1 > 0.f ? b1 : a1 * b1;
         }
+    }
+    // h1 with its two neighbours in time: zero outside the scene, the partner lane's edge value across the half boundary
+    float he[C][TL + 2];
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) {
+#pragma unroll
+        for (int t = 0; t < TL; ++t) he[ci][t + 1] = ds[ci][t];
+        float lo = 0.f, hi = 0.f;
+        if (HALF) {
+            const float p_last = __shfl_xor(ds[ci][TL - 1], 32, 64), p_first = __shfl_xor(ds[ci][0], 32, 64);
+            lo = hh == 1 ? p_last : 0.f;
+            hi = hh == 0 ? p_first : 0.f;
+        }
+        he[ci][0] = lo;
+        he[ci][TL + 1] = hi;
     }
 #pragma unroll
     for (int dt = 0; dt < KT; ++dt) {
@@ -858,14 +879,12 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
 #pragma unroll
         for (int k = 0; k < C * C; ++k) sw[k] = 0.f;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int th = t + dt - 1;                 // h1 time step of this tap (zero-padded outside 0..T-1)
-            if (th >= 0 && th < T) {
+        for (int t = 0; t < TL; ++t) {                 // h1 at time t + dt - 1
+            if (!HALF && (t + dt - 1 < 0 || t + dt - 1 >= T)) continue;   // a known zero
 #pragma unroll
-                for (int c = 0; c < C; ++c)
+            for (int c = 0; c < C; ++c)
 #pragma unroll
-                    for (int ci = 0; ci < C; ++ci) sw[c * C + ci] = fmaf(h2[c][t], ds[ci][th], sw[c * C + ci]);
-            }
+                for (int ci = 0; ci < C; ++ci) sw[c * C + ci] = fmaf(h2[c][t], he[ci][t + dt], sw[c * C + ci]);
         }
         wave_sum_n<C * C>(sw);
         if (lane0) {
@@ -878,15 +897,28 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
 #pragma unroll
     for (int k = 0; k < 3 * C + 1; ++k) s3[k] = 0.f;
     {
-        float dh1[C][T];
+        float dh1[C][TL];
 #pragma unroll
         for (int ci = 0; ci < C; ++ci)
 #pragma unroll
-            for (int t = 0; t < T; ++t) dh1[ci][t] = 0.f;
+            for (int t = 0; t < TL; ++t) dh1[ci][t] = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
+            // dh2 with its two neighbours in time (as h1 above)
+            float de[TL + 2];
 #pragma unroll
-            for (int t = 0; t < T; ++t) s3[c] += h2[c][t];
+            for (int t = 0; t < TL; ++t) {
+                de[t + 1] = h2[c][t];
+                s3[c] += h2[c][t];
+            }
+            float lo = 0.f, hi = 0.f;
+            if (HALF) {
+                const float p_last = __shfl_xor(h2[c][TL - 1], 32, 64), p_first = __shfl_xor(h2[c][0], 32, 64);
+                lo = hh == 1 ? p_last : 0.f;
+                hi = hh == 0 ? p_first : 0.f;
+            }
+            de[0] = lo;
+            de[TL + 1] = hi;
 #pragma unroll
             for (int ci = 0; ci < C; ++ci)
 #pragma unroll
@@ -894,9 +926,9 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
                     const float wv = P_[b.tcn_w + (c * C + ci) * KT + dt];
                     // dh1[ci][t] += W[c][ci][dt] dh2[c][t - dt + 1]
 #pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        const int to = t - dt + 1;
-                        if (to >= 0 && to < T) dh1[ci][t] = fmaf(wv, h2[c][to], dh1[ci][t]);
+                    for (int t = 0; t < TL; ++t) {
+                        if (!HALF && (t + 1 - dt < 0 || t + 1 - dt >= T)) continue;   // a known zero
+                        dh1[ci][t] = fmaf(wv, de[t + 2 - dt], dh1[ci][t]);
                     }
                 }
         }
@@ -904,7 +936,7 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
         for (int c = 0; c < C; ++c) {
             const float g1 = P_[b.bn1_g + c], b1p = P_[b.bn1_b + c];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < TL; ++t) {
                 const float x1 = (g[c][t] - m1[c]) * r1[c];
                 const float b1 = fmaf(x1, g1, b1p);
                 float db = dh1[c][t];
@@ -939,7 +971,7 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
             const float mdb = train ? s3[C + c] * inv_cnt : 0.f, mdbx = train ? s3[2 * C + c] * inv_cnt : 0.f;
             const float k1 = P_[b.bn1_g + c] * r1[c];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < TL; ++t) {
                 const float dg = act ? k1 * (ds[c][t] - mdb - g[c][t] * mdbx) : 0.f;
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) s4[c * CIN + ci] = fmaf(dg, ax[ci][t], s4[c * CIN + ci]);

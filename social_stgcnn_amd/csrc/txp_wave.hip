@@ -605,7 +605,8 @@ __device__ __forceinline__ void dgrad_layer(const float (&wreg)[27], const float
 // chain left d(a_0) position-major in `dcur` ([pos][P], channels 0..T-1); the dz plane is dead, so the block's three
 // LDS arrays are carved from the start of the wave's region: D = d(block output) [C][T][vi] | h1 [C][T+2][vi] | dh2
 // [C][T+2][vi] (140 vi floats <= plane_slot + 60 V); db1 reuses D.  Small-parameter gradients leave as the scene's own
-// row (stores, no atomics): reduce_slabs_kernel sums the rows in a fixed order.
+// row (stores, no atomics): reduce_slabs_kernel sums the rows in a fixed order.  V32: the caller guarantees vi <= 32.
+template <bool V32 = false>
 __device__ __forceinline__ void txp_bwd_block_tail(const TxpBwdArgs &a, const float *blk_params, int n, int vi,
                                                    float *dzb, float *dcur, ptab_t *ptab, float *tot, float *slope_row,
                                                    bool d_ready = false) {
@@ -622,13 +623,15 @@ __device__ __forceinline__ void txp_bwd_block_tail(const TxpBwdArgs &a, const fl
         }
     __builtin_amdgcn_wave_barrier();
     float *row = slope_row - L.n_blk_params;
-    if (vi <= 64 && !STG_SKIP(a, 8192)) {
+    if (V32 || (vi <= 64 && !STG_SKIP(a, 8192))) {
         // column mode: lane = pedestrian, all 8 time steps in registers (the mirror of the forward's column mode)
-        stgcn_block_bwd_cols(a, blk_params, L.blk[0], n, vi, D, row, a.ws + n * a.ws_stride);
+        if (V32 || vi <= 32) stgcn_block_bwd_cols<true>(a, blk_params, L.blk[0], n, vi, D, row, a.ws + n * a.ws_stride);
+        else stgcn_block_bwd_cols<false>(a, blk_params, L.blk[0], n, vi, D, row, a.ws + n * a.ws_stride);
         return;
     }
-    stgcn_block_bwd<Cfg::CIN0, 0, false>(a, blk_params, L.blk[0], n, vi, D, H1, DH2, D, nullptr, tot, row,
-                                         a.ws + n * a.ws_stride, nullptr, nullptr, nullptr, nullptr, ptab);
+    if (!V32)
+        stgcn_block_bwd<Cfg::CIN0, 0, false>(a, blk_params, L.blk[0], n, vi, D, H1, DH2, D, nullptr, tot, row,
+                                             a.ws + n * a.ws_stride, nullptr, nullptr, nullptr, nullptr, ptab);
 }
 
 __device__ __forceinline__ void txp_bwd_scene(const TxpBwdArgs &a, const float *blk_params, int n, float *dzb, float *dcur,
@@ -1229,7 +1232,7 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
         }
     }
     __builtin_amdgcn_wave_barrier();
-    txp_bwd_block_tail(a, blk_params, n, vi, region, nullptr, ptab, tot, slope_row, true);
+    txp_bwd_block_tail<true>(a, blk_params, n, vi, region, nullptr, ptab, tot, slope_row, true);
 }
 
 template <int WPB>
