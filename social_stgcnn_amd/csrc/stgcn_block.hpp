@@ -457,7 +457,10 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
 // LDS).  P_ / B_: the block's parameters / running statistics (the workgroup's LDS copy).  First-block shape only:
 // CIN0 input channels, residual = conv + BN (2) or none (0).
 // ------------------------------------------------------------------------------------------
-template <typename Args>
+// HALF (V_n <= 32, register hand-over only): lane = (pedestrian, time half) -- lanes 0..31 own t = 0..3, lanes 32..63
+// t = 4..7; the temporal conv's taps across the half boundary come from the partner lane (lane ^ 32), and `regs_out`
+// receives the 20 outputs f = 20*half .. 20*half+19 of the pedestrian (plane channels 4*half .. 4*half+3 of its 5 rows).
+template <bool HALF = false, typename Args>
 __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float *P_, const float *B_, const BlockLayout &b,
                                                      int n, int vi, float *wsn, float *statn, const float *pre_ax,
                                                      const float *pre_cs, float *plane, int plane_sc, float *plane_base,
@@ -466,33 +469,36 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
     // handed back instead of written to `plane` (the exact-bf16 forward splits and stores them itself)
     constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, CIN = Cfg::CIN0;
     [[maybe_unused]] constexpr int WAVES = 0;          // (diagnostic stamps)
-    const int w = threadIdx.x & 63, V = a.V;
-    const bool act = w < vi;
+    constexpr int TL = HALF ? T / 2 : T;               // time steps of a lane
+    const int lane = threadIdx.x & 63, V = a.V;
+    const int w = HALF ? lane & 31 : lane, hh = HALF ? lane >> 5 : 0, toff = TL * hh;
+    const bool act = w < vi, lane0 = lane == 0;
     const float fact = act ? 1.f : 0.f;
     const int cnt = T * vi;
     const bool train = a.lay.bn_mode == 1;
     const float eps = a.lay.eps, inv_cnt = 1.0f / (float)cnt;
     float *wsa = wsn ? wsn + a.lay.ws_hdr_floats : nullptr;
     // ---- inputs of pedestrian w: block input x (strided view), aggregated input ax, colsum cs ----------------
-    float x[CIN][T], g[C][T];
+    float x[CIN][TL], g[C][TL];
     {
-        float ax[CIN][T], cs[T];
+        float ax[CIN][TL], cs[TL];
         const float *xn = a.x + n * a.x_sn + w * a.x_sv;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            cs[t] = act ? pre_cs[t * vi + w] : 0.f;
+        for (int t = 0; t < TL; ++t) {
+            const int tg = toff + t;                   // the lane's time step t is step tg of the scene
+            cs[t] = act ? pre_cs[tg * vi + w] : 0.f;
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) {
-                ax[ci][t] = act ? pre_ax[(ci * T + t) * vi + w] : 0.f;
-                x[ci][t] = act ? xn[ci * a.x_sc + t * a.x_st] : 0.f;
+                ax[ci][t] = act ? pre_ax[(ci * T + tg) * vi + w] : 0.f;
+                x[ci][t] = act ? xn[ci * a.x_sc + tg * a.x_st] : 0.f;
             }
         }
         // (while those loads are in flight) the TXP plane image: zeros everywhere but the interior this block writes
         // at the end; the scene's position table
         {
             float4 *z4 = reinterpret_cast<float4 *>(plane_base);
-            for (int e = w; e < plane_zero_f4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int p = w; p < T * vi; p += 64) {
+            for (int e = lane; e < plane_zero_f4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = lane; p < T * vi; p += 64) {
                 const int h = p / vi;
                 qtab[p] = (ptab_t)((h << 8) | (p - h * vi));
             }
@@ -505,12 +511,12 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) wg[ci] = P_[b.gcn_w + c * CIN + ci];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < TL; ++t) {
                 float v = bg * cs[t];
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) v = fmaf(wg[ci], ax[ci][t], v);
                 g[c][t] = v;
-                if (wsa && act) wsa[(int64_t)b.ws_g * V + (c * T + t) * vi + w] = v;
+                if (wsa && act) wsa[(int64_t)b.ws_g * V + (c * T + toff + t) * vi + w] = v;
             }
         }
     }
@@ -523,7 +529,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
         for (int c = 0; c < C; ++c) {
             s1[c] = 0.f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) s1[c] += g[c][t];            // (inactive lanes hold zeros)
+            for (int t = 0; t < TL; ++t) s1[c] += g[c][t];            // (inactive lanes hold zeros)
         }
         wave_sum_n<C>(s1);
 #pragma unroll
@@ -531,7 +537,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
             m1[c] = s1[c] * inv_cnt;
             float s = 0.f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < TL; ++t) {
                 const float d = g[c][t] - m1[c];
                 s = fmaf(d, d, s);
             }
@@ -541,7 +547,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             r1[c] = 1.0f / sqrtf(s2[c] * inv_cnt + eps);
-            if (statn && w == 0) {
+            if (statn && lane0) {
                 statn[b.stat + c] = m1[c];
                 statn[b.stat + C + c] = s2[c] / (float)(cnt - 1);
             }
@@ -560,7 +566,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
         for (int c = 0; c < C; ++c) {
             const float ga = P_[b.bn1_g + c], be = P_[b.bn1_b + c];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < TL; ++t) {
                 const float v = fmaf((g[c][t] - m1[c]) * r1[c], ga, be);
                 g[c][t] = v > 0.f ? v : al * v;                    // h1
             }
@@ -568,26 +574,42 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
     }
     STG_BLK_STAMP(11);
     // ---- temporal conv tcn.2 (all taps in this lane's registers) ----------------------------------------
-    float h2[C][T];
+    // h1 with its two neighbours in time: zero outside the scene, the partner lane's edge value across the half boundary
+    float he[C][TL + 2];
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) {
+#pragma unroll
+        for (int t = 0; t < TL; ++t) he[ci][t + 1] = g[ci][t];
+        float lo = 0.f, hi = 0.f;
+        if (HALF) {
+            const float p_last = __shfl_xor(g[ci][TL - 1], 32, 64), p_first = __shfl_xor(g[ci][0], 32, 64);
+            lo = hh == 1 ? p_last : 0.f;
+            hi = hh == 0 ? p_first : 0.f;
+        }
+        he[ci][0] = lo;
+        he[ci][TL + 1] = hi;
+    }
+    float h2[C][TL];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const float tb = P_[b.tcn_b + c];
 #pragma unroll
-        for (int t = 0; t < T; ++t) h2[c][t] = tb;
+        for (int t = 0; t < TL; ++t) h2[c][t] = tb;
 #pragma unroll
         for (int ci = 0; ci < C; ++ci)
 #pragma unroll
             for (int dt = 0; dt < KT; ++dt) {
                 const float wv = P_[b.tcn_w + (c * C + ci) * KT + dt];
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const int ti = t + dt - (KT - 1) / 2;
-                    if (ti >= 0 && ti < T) h2[c][t] = fmaf(wv, g[ci][ti], h2[c][t]);
+                for (int t = 0; t < TL; ++t) {
+                    const int ti = t + dt - (KT - 1) / 2;           // h1 time step of this tap
+                    if (!HALF && (ti < 0 || ti >= T)) continue;      // a known zero
+                    h2[c][t] = fmaf(wv, he[ci][ti + 1], h2[c][t]);
                 }
             }
         if (wsa && act) {
 #pragma unroll
-            for (int t = 0; t < T; ++t) wsa[(int64_t)b.ws_h2 * V + (c * T + t) * vi + w] = h2[c][t];
+            for (int t = 0; t < TL; ++t) wsa[(int64_t)b.ws_h2 * V + (c * T + toff + t) * vi + w] = h2[c][t];
         }
     }
     STG_BLK_STAMP(12);
@@ -611,7 +633,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) rw[ci] = b.residual == 2 ? P_[b.res_w + c * CIN + ci] : 0.f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < TL; ++t) {
                 s += h2[c][t];
                 if (b.residual == 2) sr += res_val(c, t, rb, rw);
             }
@@ -629,7 +651,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
             for (int ci = 0; ci < CIN; ++ci) rw[ci] = b.residual == 2 ? P_[b.res_w + c * CIN + ci] : 0.f;
             float v = 0.f, vr = 0.f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < TL; ++t) {
                 const float d = h2[c][t] - m2[c];
                 v = fmaf(d, d, v);
                 if (b.residual == 2) {
@@ -645,7 +667,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
         for (int c = 0; c < C; ++c) {
             r2[c] = 1.0f / sqrtf(sv2[c] * inv_cnt + eps);
             rr[c] = 1.0f / sqrtf((b.residual == 2 ? sv2[C + c] * inv_cnt : 0.f) + eps);
-            if (statn && w == 0) {
+            if (statn && lane0) {
                 statn[b.stat + 2 * C + c] = m2[c];
                 statn[b.stat + 3 * C + c] = sv2[c] / (float)(cnt - 1);
                 if (b.residual == 2) {
@@ -666,7 +688,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
         }
     }
     STG_BLK_STAMP(13);
-    if (wsn && w == 0) {
+    if (wsn && lane0) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             wsn[b.ws_hdr + c] = m1[c];
@@ -683,6 +705,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
     const float ao = P_[b.prelu_o];
     const int SW = txp_sw(vi);
     float *pw = plane + (w + 1);
+    [[maybe_unused]] float so[C][TL];                  // (HALF) the lane's outputs before the hand-over
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const float g2 = P_[b.bn2_g + c], b2 = P_[b.bn2_b + c];
@@ -692,15 +715,37 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
 #pragma unroll
         for (int ci = 0; ci < CIN; ++ci) rw[ci] = b.residual == 2 ? P_[b.res_w + c * CIN + ci] : 0.f;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
+        for (int t = 0; t < TL; ++t) {
             float u = fmaf((h2[c][t] - m2[c]) * r2[c], g2, b2);
             if (b.residual == 2) u += fmaf((res_val(c, t, rb, rw) - mr[c]) * rr[c], gr, br);
             const float s = (a.lay.use_mdn || u > 0.f) ? u : ao * u;
-            // v.view(N, T, C, V) (model.py:187): flat plane index f = c*T+t -> (f / C, f % C), static here
-            constexpr int dummy = 0; (void)dummy;
-            const int f = c * T + t, ch = f / C, row = f - ch * C;
-            if (regs_out) regs_out[f] = act ? s : 0.f;
-            else if (act) pw[ch * plane_sc + (row + 1) * SW] = s;
+            if constexpr (HALF) {
+                so[c][t] = act ? s : 0.f;
+            } else {
+                // v.view(N, T, C, V) (model.py:187): flat plane index f = c*T+t -> (f / C, f % C), static here
+                const int f = c * T + t, ch = f / C, row = f - ch * C;
+                if (regs_out) regs_out[f] = act ? s : 0.f;
+                else if (act) pw[ch * plane_sc + (row + 1) * SW] = s;
+            }
+        }
+    }
+    if constexpr (HALF) {
+        // The pedestrian's 40 outputs f = c*T + t; half 0 hands over f = 0..19 (c = 0, 1 and t < 4 of c = 2), half 1
+        // f = 20..39 (t >= 4 of c = 2 and c = 3, 4): each lane is short of two channels' other time half, which the
+        // partner lane holds.
+        static_assert(!HALF || (C == 5 && T == 8), "the hand-over below is written for the 5 x 8 block output");
+        float rcv[2][TL];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < TL; ++k) rcv[i][k] = __shfl_xor(hh == 0 ? so[3 + i][k] : so[i][k], 32, 64);
+#pragma unroll
+        for (int k = 0; k < TL; ++k) {
+            regs_out[k] = hh == 0 ? so[0][k] : so[2][k];
+            regs_out[4 + k] = rcv[0][k];
+            regs_out[8 + k] = hh == 0 ? so[1][k] : so[3][k];
+            regs_out[12 + k] = rcv[1][k];
+            regs_out[16 + k] = hh == 0 ? so[2][k] : so[4][k];
         }
     }
     __builtin_amdgcn_wave_barrier();

@@ -469,24 +469,25 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
 
     // ---- st_gcn block (model.py:145-155), column mode: lane = pedestrian; zeroes the image, builds the position table
     {
-        float sv[C * T];
+        // lane = (pedestrian, time half); a lane receives plane channels 4*half .. 4*half+3 of its pedestrian's C rows
+        float sv[C * T / 2];
         const float *agn = a.agg + n * a.agg_stride;
-        stgcn_block_fwd_cols(a, blk_params, blk_buffers, L.blk[0], n, vi, wsn, statn, agn + a.agg_ax, agn + a.agg_cs, nullptr,
-                             0, region, cv::image_bytes(vi, kF6Slots) >> 4, ptab, sv);
+        stgcn_block_fwd_cols<true>(a, blk_params, blk_buffers, L.blk[0], n, vi, wsn, statn, agn + a.agg_ax, agn + a.agg_cs,
+                                   nullptr, 0, region, cv::image_bytes(vi, kF6Slots) >> 4, ptab, sv);
         // v.view(N, T, C, V) (model.py:187): flat f = c*T+t of the block output is plane channel f / C, row f % C.  Per
-        // row the lane's eight channels are two record quads; the third quad (channels 8..11) stays zero.
+        // row a pedestrian's eight channels are two record quads (one per lane of the pair); the third quad (channels
+        // 8..11) stays zero.
         float *d2 = wsn ? wsn + ws_plane_off(L, V, 0) : nullptr;
-        if (lane < vi) {
+        const int pw = lane & 31, q = lane >> 5;
+        if (pw < vi) {
 #pragma unroll
             for (int row = 0; row < C; ++row) {
-#pragma unroll
-                for (int q = 0; q < T / 4; ++q) {
-                    const f32x4 v4 = {sv[(4 * q + 0) * C + row], sv[(4 * q + 1) * C + row], sv[(4 * q + 2) * C + row],
-                                      sv[(4 * q + 3) * C + row]};
-                    cv::put4(img, (unsigned)(cv::pos_off(vi, 1 + row, lane) + 8 * q), lg.PL, v4);
-                    if (d2) store_vec4(d2, (row * SWs + lane + 1) * 3 + q, v4, bf16);
+                const f32x4 v4 = {sv[row], sv[C + row], sv[2 * C + row], sv[3 * C + row]};
+                cv::put4(img, (unsigned)(cv::pos_off(vi, 1 + row, pw) + 8 * q), lg.PL, v4);
+                if (d2) {
+                    store_vec4(d2, (row * SWs + pw + 1) * 3 + q, v4, bf16);
+                    if (q == 0) store_vec4(d2, (row * SWs + pw + 1) * 3 + 2, f32x4{0.f, 0.f, 0.f, 0.f}, bf16);
                 }
-                if (d2) store_vec4(d2, (row * SWs + lane + 1) * 3 + 2, f32x4{0.f, 0.f, 0.f, 0.f}, bf16);
             }
         }
         if (wsn && lane < 2 * C * 3) {
