@@ -125,7 +125,7 @@ typedef struct {
                                * where the default uses v_mfma_f32_16x16x32_bf16 with exact three-piece operands (V <= 32, fp32
                                * storage): same accuracy class, for A/B measurements                                            */
 #define STG_OPT_WAVE_PATH 4   /* keep the wave-per-scene kernels for small batches too (default: batches of fewer than  */
-                              /* 768 scenes of <= 40 pedestrians run the workgroup kernels, several waves per scene)     */
+                              /* 513 scenes of <= 40 pedestrians run the workgroup kernels, several waves per scene)     */
 
 int64_t stg_model_param_count(const stg_model_desc *d);
 int64_t stg_model_buffer_count(const stg_model_desc *d);
@@ -170,8 +170,8 @@ int stg_model_bwd(const stg_model_desc *d, const float *params, const float *buf
  * backward starts from V_pred itself -- y, the (N, 5, pred, V) output of stg_model_fwd -- and the (N, pred, V, 2)
  * target, computes d(sum_n weights[n] * loss_n)/dV_pred in its input stage (metrics.py:84-113, as stg_nll_fwd does)
  * and writes losses[n] = bivariate_loss of scene n.  weights may be NULL (all ones).  Served by the wave-per-scene
- * kernels only: STG_EUNSUPPORTED (nothing launched, no error message) on the workgroup path or with
- * STG_OPT_SPLIT_BF16 -- call stg_nll_fwd + stg_model_bwd then.  No input gradient.                                 */
+ * and the workgroup-per-scene kernels alike; STG_EUNSUPPORTED (nothing launched, no error message) with
+ * STG_OPT_SPLIT_BF16 or without a TXP-CNN -- call stg_nll_fwd + stg_model_bwd then.  No input gradient.            */
 int stg_model_bwd_nll(const stg_model_desc *d, const float *params, const float *buffers, const float *x, int64_t x_sn,
                       int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj, int64_t a_sn, const int32_t *num_peds,
                       int N, int V, const float *y, const float *target, const float *weights, float *losses,

@@ -29,6 +29,7 @@
 #include "txp_wave.hpp"
 #include "txp_wgrad.hpp"
 #include "tail_parts.hpp"
+#include "nll_elem.hpp"
 
 namespace stg {
 
@@ -41,6 +42,9 @@ struct BwdArgs {
     const int32_t *num_peds;
     int N, V;
     const float *dy, *ws;
+    // fused loss (stg_model_bwd_nll / _step): dy is V_pred (N, 5, P, V) and the kernel computes dV_pred itself
+    const float *nll_target, *nll_weights;
+    float *nll_losses;
     int64_t ws_stride;
     float *slab1;     // K1 slab rows: [gridDim.x][n_blk_params + n_txp]
     float *dzg;       // dz_l of the hidden TXP layers for K2: [N][L][P*C*V]
@@ -117,6 +121,42 @@ __device__ void txp_dgrad(const float *__restrict__ W, const float *dzb, float *
     }
 }
 
+// Fused loss of the workgroup-per-scene backward (stg_model_bwd_nll / _step): `yn` is the scene's V_pred (5, P, V); a
+// thread takes (prediction step p, pedestrian w) and writes its five gradients -- rows f * P + p of the (C*P) x V array
+// the input-gradient chain starts from -- into the dz plane and, position-major, into the weight-gradient GEMM's copy.
+// Out of line: inlined, its live range pushed the kernel to 260 registers and one workgroup per SIMD pair.
+__device__ __noinline__ void bwd_nll_stage(const float *yn, const float *tn, float weight, int vi, int V, int SC, int SW,
+                                           float *dzb, float *dzo, float *nll_part, float *loss_out) {
+    constexpr int C = Cfg::C, P = Cfg::P;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const float inv_cnt = 1.0f / (float)(P * vi);
+    const float gs = inv_cnt * weight;
+    float lacc = 0.f;
+    for (int e = tid; e < P * vi; e += nt) {
+        const int p = e / vi, w = e - p * vi;
+        const float *q = yn + (int64_t)p * V + w;
+        const float2 tg = *reinterpret_cast<const float2 *>(tn + ((int64_t)p * V + w) * 2);
+        float g[5];
+        lacc += nll_elem(q[0], q[(int64_t)P * V], q[(int64_t)2 * P * V], q[(int64_t)3 * P * V], q[(int64_t)4 * P * V], tg.x,
+                         tg.y, true, g);
+#pragma unroll
+        for (int f = 0; f < C; ++f) {
+            const int rc = f * P + p, ch = rc / C, h = rc - ch * C;
+            const float dv = g[f] * gs;
+            dzb[ch * SC + (h + 1) * SW + (w + 1)] = dv;
+            dzo[(h * vi + w) * P + ch] = dv;
+        }
+    }
+    lacc = wave_sum(lacc);
+    if ((tid & 63) == 0) nll_part[tid >> 6] = lacc;
+    __syncthreads();
+    if (tid == 0) {                                    // fixed order: the same loss bits on every run
+        float s = 0.f;
+        for (int k = 0; k < nt >> 6; ++k) s += nll_part[k];
+        *loss_out = s * inv_cnt;
+    }
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, const float *params) {
     // (unlike the forward kernel, params is NOT __restrict__ here: scalar-loading the weights into SGPRs pushed
@@ -139,6 +179,7 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
     float *red = dcur + dcur_floats;                  // [WAVES*kRedMax]
     float *tot = red + WAVES * kRedMax;               // [kRedMax]
     const float *Pm = params;
+    __shared__ float nll_part[WAVES];                 // (fused loss) per-wave partial sums of the scene's loss
 
     for (int e = tid; e < n_small; e += NT) gsm[e] = 0.f;
 
@@ -157,7 +198,10 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
                 const int r = e / (V - vi), w = vi + (e - r * (V - vi));
                 dxn[(int64_t)r * V + w] = 0.f;
             }
-        if (vi == 0) continue;
+        if (vi == 0) {
+            if (a.nll_target && tid == 0) a.nll_losses[n] = 0.f;
+            continue;
+        }
         const float *wsn = a.ws + n * a.ws_stride;
         const int SW = txp_sw(vi), SC = txp_sc(vi), npos = C * vi;
         const int out_rows = L.n_txp > 0 ? C * P : C * T;
@@ -173,6 +217,10 @@ __global__ __launch_bounds__(WAVES * 64) void model_bwd_kernel(const BwdArgs a, 
                     // (dz of the output conv is dy; it also leaves position-major for the weight-gradient GEMM)
                     float *dzo = a.dzg + ((int64_t)n * (L.L + 1) + L.L) * dz_slot(V);
                     constexpr int U = 4;
+                    if (a.nll_target) {
+                        bwd_nll_stage(dyn, a.nll_target + (int64_t)n * P * V * 2, a.nll_weights ? a.nll_weights[n] : 1.f,
+                                      vi, V, SC, SW, dzb, dzo, nll_part, a.nll_losses + n);
+                    } else
                     for (int e0 = tid; e0 < P * npos; e0 += NT * U) {
                         float dv[U];
                         int li[U];
@@ -475,7 +523,7 @@ static int model_bwd_impl(const stg_model_desc *d, const float *params, const fl
                 "stg_model_bwd: bf16 storage (STG_OPT_BF16_STORE) is built for the wave-per-scene kernels only");
     STG_REQUIRE(!((L.flags & STG_OPT_BF16_STORE) && (L.flags & STG_OPT_SPLIT_BF16)), STG_EUNSUPPORTED,
                 "stg_model_bwd: STG_OPT_BF16_STORE and STG_OPT_SPLIT_BF16 cannot be combined");
-    if (nll_target && (!wave_path || (L.flags & STG_OPT_SPLIT_BF16) || L.n_txp == 0))
+    if (nll_target && ((L.flags & STG_OPT_SPLIT_BF16) || L.n_txp == 0))
         return STG_EUNSUPPORTED;        // (no message: the caller falls back to stg_nll_fwd + stg_model_bwd)
     STG_REQUIRE(!(wave_path && dx), STG_EUNSUPPORTED,
                 "stg_model_bwd: dx is only computed by the workgroup-per-scene kernels: set STG_OPT_WG_PATH in the "
@@ -483,6 +531,7 @@ static int model_bwd_impl(const stg_model_desc *d, const float *params, const fl
     a.params = params; a.buffers = buffers; a.x = x;
     a.x_sn = x_sn; a.x_sc = x_sc; a.x_st = x_st; a.x_sv = x_sv;
     a.adj = adj; a.a_sn = a_sn; a.num_peds = num_peds; a.N = N; a.V = V;
+    a.nll_target = nll_target; a.nll_weights = nll_weights; a.nll_losses = nll_losses;
     a.dy = dy; a.ws = ws; a.ws_stride = ws_floats_per_scene(L, V); a.slab1 = rows; a.dzg = dzg; a.dx = dx;
     // ragged batch: sorted scene list at the tail of the scratch buffer
     int32_t *order = reinterpret_cast<int32_t *>(scratch + cv.order);

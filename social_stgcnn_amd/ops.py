@@ -179,7 +179,7 @@ class FlatPack:
 #   wg_path     run the workgroup-per-scene kernels even where the wave-per-scene path fits (tests cover both)
 #   split_bf16  TXP input-gradient GEMMs on bf16 MFMAs with hi/lo-split operands (opt-in, fp32 in / out)
 #   wg_waves    0 = auto, or 1 / 2 / 4 / 8 waves per scene in the workgroup-per-scene kernels
-#   wave_path   keep the wave-per-scene kernels for small batches too (default: batches below 768 scenes of <= 40
+#   wave_path   keep the wave-per-scene kernels for small batches too (default: batches of up to 512 scenes of <= 40
 #               pedestrians run the workgroup kernels with 4 or 8 waves per scene -- one wave per scene would leave
 #               most of the chip's wave slots empty)
 #   bf16_store  bf16 storage of the saved TXP activations and of the dz hand-off (STG_OPT_BF16_STORE): fp32 forward
@@ -359,8 +359,8 @@ def backward_from_target(holder, y, target, weights=None, step=None):
     """Loss + backward of the fused forward `holder` (a model) just ran, in the backward's own launches
     (stg_model_bwd_nll): per-scene bivariate losses (N,) are returned, the parameter gradients of
     sum_n weights[n] * loss_n land in `holder._flat_grad` and in every live parameter's .grad (views of it).
-    Returns None -- nothing launched -- when the batch runs the workgroup-per-scene kernels: the caller then takes the
-    separate loss kernel + autograd backward.
+    Returns None -- nothing launched -- where the library has no fused form (STG_OPT_SPLIT_BF16, a model without a
+    TXP-CNN): the caller then takes the separate loss kernel + autograd backward.
 
     step = (pending_bn, lr, lr_dev): the rest of a single-rank training step rides in the same launches
     (stg_model_bwd_step: SGD without clipping on the flat parameters, the BatchNorm fold of `pending_bn` -- what a

@@ -234,7 +234,8 @@ def test_step_tail_launch_equals_its_three_separate_launches(dev, clip):
 def test_fused_loss_backward_equals_loss_kernel_then_backward(dev):
     """stg_model_bwd_nll (the backward's input stage computes dV_pred from V_pred and the target) against
     stg_nll_fwd + stg_model_bwd on the same ragged batch (an empty scene, per-scene weights incl. a zero): per-scene
-    losses and every parameter gradient; and the workgroup path reports 'unsupported' so the trainer falls back."""
+    losses and every parameter gradient, on the wave-per-scene and the workgroup-per-scene kernels; split-bf16 operands
+    report 'unsupported' so the trainer falls back."""
     import bench
     from social_stgcnn_amd import ops
     from social_stgcnn_amd.model import social_stgcnn
@@ -275,10 +276,30 @@ def test_fused_loss_backward_equals_loss_kernel_then_backward(dev):
         scale = max(0.05 * gmax, float(ref.abs().max()))
         assert float((fused[k] - ref).abs().max()) <= 2e-6 * scale, k
     del state
-    # workgroup-per-scene kernels: nothing fused, the caller is told so
-    ops.OPTIONS["wg_path"] = True
+    # the workgroup-per-scene kernels (small batches) fuse the loss the same way; split-bf16 operands: nothing fused,
+    # the caller is told so
+    for waves in (0, 1, 4):
+        ops.OPTIONS["wg_path"], ops.OPTIONS["wg_waves"] = True, waves
+        try:
+            for p in m2.parameters():
+                p.grad = None
+            y3, _ = m2(x, adj, peds)
+            l3 = ops.backward_from_target(m2, y3.detach(), tgt, w)
+            assert l3 is not None
+            assert torch.allclose(l3.cpu(), l2.cpu(), rtol=2e-6, atol=1e-6)
+            assert float(l3[7]) == 0.0
+            for k, p in m2.named_parameters():
+                if fused[k] is None:
+                    assert p.grad is None, k
+                    continue
+                # (other kernels, another summation order: compared on the scale of the largest gradient -- the
+                # rounding noise of an exactly-zero bias gradient is of that scale)
+                assert float((p.grad.detach().cpu() - fused[k]).abs().max()) <= 1e-5 * gmax, (waves, k)
+        finally:
+            ops.OPTIONS["wg_path"], ops.OPTIONS["wg_waves"] = False, 0
+    ops.OPTIONS["split_bf16"] = True
     try:
-        y3, _ = m2(x, adj, peds)
-        assert ops.backward_from_target(m2, y3.detach(), tgt, w) is None
+        y4, _ = m2(x, adj, peds)
+        assert ops.backward_from_target(m2, y4.detach(), tgt, w) is None
     finally:
-        ops.OPTIONS["wg_path"] = False
+        ops.OPTIONS["split_bf16"] = False
