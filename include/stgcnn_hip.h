@@ -133,8 +133,9 @@ int64_t stg_model_buffer_count(const stg_model_desc *d);
 int64_t stg_model_ws_floats(const stg_model_desc *d, int V);
 /* floats of the BATCH tail of the training workspace, behind the N per-scene blocks: the forward leaves there what the
  * backward needs once per batch (the prepared bf16 operands of the input-gradient GEMMs, written by extra workgroups
- * of the forward's first launch).  ws holds N * stg_model_ws_floats + stg_model_ws_tail_floats floats.              */
-int64_t stg_model_ws_tail_floats(const stg_model_desc *d, int V);
+ * of the forward's first launch; the scene order of a ragged batch, so that the backward does not sort again -- it
+ * must be given the forward's num_peds).  ws holds N * stg_model_ws_floats + stg_model_ws_tail_floats floats.      */
+int64_t stg_model_ws_tail_floats(const stg_model_desc *d, int N, int V);
 /* Per-scene batch statistics the forward emits in bn_mode 1: (N, stat_floats) =
  * per block, per BatchNorm: mean[C], unbiased var[C].                                           */
 int64_t stg_model_stat_floats(const stg_model_desc *d);

@@ -46,7 +46,7 @@ _SIGNATURES = {
     "stg_model_param_count": (c_l, [ctypes.POINTER(ModelDesc)]),
     "stg_model_buffer_count": (c_l, [ctypes.POINTER(ModelDesc)]),
     "stg_model_ws_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i]),
-    "stg_model_ws_tail_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i]),
+    "stg_model_ws_tail_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i, c_i]),
     "stg_model_stat_floats": (c_l, [ctypes.POINTER(ModelDesc)]),
     "stg_model_fwd_scratch_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i, c_i]),
     "stg_model_bwd_scratch_floats": (c_l, [ctypes.POINTER(ModelDesc), c_i, c_i]),

@@ -535,8 +535,16 @@ static int model_bwd_impl(const stg_model_desc *d, const float *params, const fl
     a.dy = dy; a.ws = ws; a.ws_stride = ws_floats_per_scene(L, V); a.slab1 = rows; a.dzg = dzg; a.dx = dx;
     // ragged batch: sorted scene list at the tail of the scratch buffer
     int32_t *order = reinterpret_cast<int32_t *>(scratch + cv.order);
+    bool sorted;
+    if (wave_path && scene_order_applies(num_peds, N, V)) {
+        // the wave-per-scene forward left its order in the workspace's batch tail (stg_model_ws_tail_floats)
+        order = reinterpret_cast<int32_t *>(const_cast<float *>(ws) + (int64_t)N * ws_floats_per_scene(L, V) +
+                                            ws_tail_wp_floats(L, V));
+        sorted = true;
+    } else {
+        sorted = launch_scene_order(num_peds, N, V, order, order + N, st, order + N + V + 2);
+    }
     int32_t *order_peds = order + N + V + 2;
-    const bool sorted = launch_scene_order(num_peds, N, V, order, order + N, st, order_peds);
     const int serp = diag_env("STG_WALK", 1);
     a.tier = SceneTier{sorted ? order : nullptr, sorted ? order + N : nullptr, -1, V, serp};
     a.debug_skip = diag_env("STG_DEBUG_SKIP", 0);

@@ -142,6 +142,11 @@ __host__ __device__ inline int64_t order_floats(int N, int V) { return ((int64_t
 // order_peds (optional): order_peds[i] = clamp(num_peds[order[i]], 0, V), the sorted counts themselves.
 bool launch_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, int32_t *key_start, hipStream_t st,
                         int32_t *order_peds = nullptr);
+// whether launch_scene_order sorts such a batch at all (the training forward leaves its order in the workspace's batch
+// tail and the backward picks it up instead of sorting again: both sides decide with this)
+inline bool scene_order_applies(const int32_t *num_peds, int N, int V) {
+    return num_peds && N >= 2 && N <= kOrderMaxN && V <= kOrderMaxV;
+}
 
 // stgcn_agg.hip: ax = x A ([cin][T][V_n]) and cs = colsum(A) ([T][V_n]) of every scene -- the one read of A in a
 // step -- written to out + n * out_stride + ax_off / cs_off.

@@ -235,12 +235,16 @@ static int64_t fwd_wp_off(const ModelLayout &l, int N, int V, bool stamps) {
 
 }  // namespace stg
 
-extern "C" int64_t stg_model_ws_tail_floats(const stg_model_desc *d, int V) {
+// batch tail of the training workspace: [prepared operands of the exact-bf16 input-gradient chain | scene order]
+namespace stg {
+int64_t ws_tail_wp_floats(const ModelLayout &l, int V) { return txp_bwd_x6_fits(l, V) ? txp_bwd_x6_wp_floats(l) : 0; }
+}
+extern "C" int64_t stg_model_ws_tail_floats(const stg_model_desc *d, int N, int V) {
     stg::ModelLayout l;
     const int rc = stg::make_layout(d, &l);
     if (rc != STG_OK) return rc;
-    if (V <= 0) return stg::fail(STG_EINVAL, "stg_model_ws_tail_floats: V=%d", V);
-    return stg::txp_bwd_x6_fits(l, V) ? stg::txp_bwd_x6_wp_floats(l) : 0;
+    if (N < 0 || V <= 0) return stg::fail(STG_EINVAL, "stg_model_ws_tail_floats: N=%d V=%d", N, V);
+    return stg::ws_tail_wp_floats(l, V) + stg::order_floats(N, V);
 }
 
 extern "C" int64_t stg_model_fwd_scratch_floats(const stg_model_desc *d, int N, int V) {
@@ -312,8 +316,11 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
     int32_t *order = reinterpret_cast<int32_t *>(scratch + fwd_agg_floats(L, N, V));
     if (wave_path) {
         // K1: ONE wave-per-scene kernel for the whole model: st_gcn block (VALU) + TXP-CNN (MFMA), the a_0 plane never
-        // leaves LDS.  Ragged batch: sorted scene list, walked boustrophedon.
-        const bool sorted = launch_scene_order(num_peds, N, V, order, order + N, st);
+        // leaves LDS.  Ragged batch: sorted scene list, walked boustrophedon.  Training: the order (with its tier offsets
+        // and the sorted counts) goes to the workspace's batch tail, where the backward finds it -- no second sort.
+        if (ws) order = reinterpret_cast<int32_t *>(ws + (int64_t)N * a.ws_stride + ws_tail_wp_floats(L, V));
+        const bool sorted = launch_scene_order(num_peds, N, V, order, order + N, st, order + N + V + 2);
+        if (!sorted && scene_order_applies(num_peds, N, V)) return hip_fail(hipErrorLaunchFailure, "stg_model_fwd: scene_order launch");
         TxpFwdArgs t{};
         t.lay = L; t.params = params; t.buffers = buffers; t.num_peds = num_peds; t.N = N; t.V = V;
         t.x = x; t.x_sn = x_sn; t.x_sc = x_sc; t.x_st = x_st; t.x_sv = x_sv;

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(1024) void scene_order_kernel(const int32_t *__rest
 
 bool launch_scene_order(const int32_t *num_peds, int N, int V, int32_t *order, int32_t *key_start, hipStream_t st,
                         int32_t *order_peds) {
-    if (!num_peds || !order || N < 2 || N > kOrderMaxN || V > kOrderMaxV) return false;
+    if (!order || !scene_order_applies(num_peds, N, V)) return false;
     const size_t lds = (size_t)(V + 1) * 16 * sizeof(int);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(&scene_order_kernel),

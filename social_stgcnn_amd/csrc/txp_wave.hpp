@@ -77,6 +77,7 @@ bool txp_wave_fits(const ModelLayout &L, int V);
 // workgroup-per-scene kernels with `*wg_waves` waves per scene instead (measured: N = 512 x 4 waves 2.9 vs 2.5 M
 // scene-windows/s, N = 128 x 8 waves 0.95 vs 0.70).  Forward and backward make the same choice from (L, N, V).
 bool use_wave_path(const ModelLayout &L, int N, int V, int *wg_waves);
+int64_t ws_tail_wp_floats(const ModelLayout &l, int V);      // model_fwd.hip: floats of the operand part of the workspace's batch tail
 int launch_txp_fwd_wave(const TxpFwdArgs &a, hipStream_t st);
 int launch_txp_bwd_wave(const TxpBwdArgs &a, hipStream_t st);
 // the exact-bf16 input-gradient chain (txp_bwd_x6): serves whole batches with V <= 32, fp32 storage

@@ -274,7 +274,7 @@ class _FusedModel(torch.autograd.Function):
             wsf = L.stg_model_ws_floats(ctypes.byref(desc), v)
             if wsf < 0:
                 check(int(wsf), "stg_model_ws_floats")
-            tail = L.stg_model_ws_tail_floats(ctypes.byref(desc), v)
+            tail = L.stg_model_ws_tail_floats(ctypes.byref(desc), n, v)
             if tail < 0:
                 check(int(tail), "stg_model_ws_tail_floats")
             ws = torch.empty(n * wsf + tail, device=x.device, dtype=torch.float32)
