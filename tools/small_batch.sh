@@ -1,3 +1,7 @@
+#!/bin/bash
+# Small batches (run through gpurun from the repo root): default path choice (workgroup-per-scene kernels up to 512
+# scenes) against the wave-per-scene kernels (--wave-path), then rocprofv3 kernel tables of both at 128 scenes -- the
+# wave-path table is the latency of ONE scene on a lone wave (profiles/r02_small_batch.log).
 for args in "--batch 128" "--batch 128 --wave-path" "--batch 256" "--batch 256 --wave-path" "--batch 512" "--batch 512 --wave-path" "--batch 1024"; do
   timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --repeats 8 --steps 20 $args 2>/dev/null | tail -1 | python3 -c "
 import json,sys
