@@ -8,7 +8,9 @@ import bench
 from social_stgcnn_amd import ops
 from social_stgcnn_amd.model import social_stgcnn
 dev = torch.device("cuda", 0)
-n, v = 2048, 32
+n, v = int(os.environ.get("STAMPS_N", "2048")), int(os.environ.get("STAMPS_V", "32"))
+ops.OPTIONS["f32_mfma"] = True          # the stamps live in the fp32-MFMA wave kernel (txp_fwd_wave_kernel)
+ops.OPTIONS["wave_path"] = True
 obs_rel, target = bench.synth_scenes(n, v, 1)
 nodes, adj = ops.adj_build(torch.from_numpy(obs_rel).to(dev))
 x = nodes.permute(0, 3, 1, 2)
