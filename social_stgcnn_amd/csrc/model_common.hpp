@@ -75,6 +75,19 @@ __device__ __forceinline__ f32x4 load_vec4(const float *base, int vec, bool bf16
     if (bf16) return unpack_bf16x4(reinterpret_cast<const uint2 *>(base)[vec]);
     return reinterpret_cast<const f32x4 *>(base)[vec];
 }
+// The same in two steps, for several loads in flight: the raw bits now (bf16 storage: the 8 bytes in lanes 0 / 1 of the
+// vector), the conversion after they have all landed -- converting right behind each load makes the loads wait for
+// one another.
+__device__ __forceinline__ f32x4 load_vec4_raw(const float *base, int vec, bool bf16) {
+    if (bf16) {
+        const uint2 r = reinterpret_cast<const uint2 *>(base)[vec];
+        return f32x4{__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f};
+    }
+    return reinterpret_cast<const f32x4 *>(base)[vec];
+}
+__device__ __forceinline__ f32x4 finish_vec4(const f32x4 &raw, bool bf16) {
+    return bf16 ? unpack_bf16x4(make_uint2(__float_as_uint(raw[0]), __float_as_uint(raw[1]))) : raw;
+}
 
 // LDS geometry of one padded TXP plane set: rows = C + 2, row stride SW = vi + 2, channel stride SC
 // chosen == 16 (mod 32) so the four K-lanes groups of a 16x16x4 B-operand read hit disjoint banks.

@@ -442,6 +442,14 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
 // the residual input of the next layer -- a lane owns the same (position, channel quad) of every tile in every layer
 // (<= 10 tiles for V_n <= 32).  The st_gcn block (column mode) hands its outputs over in registers as well.
 constexpr int kF6Tiles = 10, kF6Slots = 7;
+
+// "Every vector-memory operation issued so far has completed", stated where the compiler can see it (an S_WAITCNT it
+// models).  vmcnt counts loads AND stores in order; wherever a register MAY still be waiting for a load on some path of
+// the control-flow graph (a tile loop whose iterations are guarded by runtime tile counts is enough), the compiler puts
+// s_waitcnt vmcnt(0) in front of its use -- which also waits for the acknowledgement of every store issued since: one
+// HBM round trip per tile.  Draining once, right after the loads and before the guarded code, leaves nothing pending,
+// and the tiles' stores are fire-and-forget again.  (F 72 -> see DESIGN 5.2; found in the ISA, not in a counter.)
+__device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), expcnt / lgkmcnt free
 __host__ __device__ inline int fwd6_region_floats(int v) { return (cv::image_bytes(v, kF6Slots) / 4 + 3) & ~3; }
 
 __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const float *__restrict__ params,
@@ -516,6 +524,9 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
         const float alpha = is_out ? 0.f : Pm[L.prelus + l];
         float *zs = (wsn && !is_out) ? wsn + L.ws_hdr_floats + (int64_t)L.ws_z[l] * V : nullptr;
         float *ps = (wsn && !is_out) ? wsn + ws_plane_off(L, V, l + 1) : nullptr;
+        // the layer's operands and bias have landed before the first guarded tile: no vmcnt wait inside the tile loop
+        asm volatile("" ::"v"(w[0]), "v"(w[cv::kWpVecs - 1]), "v"(binit), "v"(alpha) : "memory");
+        vm_drain();
 #pragma unroll
         for (int t = 0; t < kF6Tiles; ++t) {
             if (t < ntiles) {
@@ -1133,6 +1144,7 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
             // scattered 4-byte store and three 2-byte LDS stores per value cost 20 us)
             // (the registers of the running input gradient are free here: the output conv's chain starts from zero)
             __builtin_amdgcn_wave_barrier();
+            vm_drain();                                 // (V_pred / target are consumed: nothing pending past here)
             f32x4 (&qd)[kX6Tiles] = dcur;
 #pragma unroll
             for (int t = 0; t < kX6Tiles; ++t) {
@@ -1171,14 +1183,20 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
             for (int t = 0; t < kX6Tiles; ++t) rec[t] = rec_of(t);
 #pragma unroll
             for (int t = 0; t < kX6Tiles; ++t)
-                zv[t] = rec[t] >= 0 ? load_vec4(zl, quad_of(t), bf16) : f32x4{1.f, 1.f, 1.f, 1.f};
+                zv[t] = rec[t] >= 0 ? load_vec4_raw(zl, quad_of(t), bf16) : f32x4{1.f, 1.f, 1.f, 1.f};
+            // all ten have landed before the first guarded tile: the tiles' dz stores are not waited for (vm_drain)
+            asm volatile("" ::"v"(zv[0]), "v"(zv[1]), "v"(zv[2]), "v"(zv[3]), "v"(zv[4]), "v"(zv[5]), "v"(zv[6]), "v"(zv[7]),
+                         "v"(zv[8]), "v"(zv[9]), "v"(alpha)
+                         : "memory");
+            vm_drain();
 #pragma unroll
             for (int t = 0; t < kX6Tiles; ++t) {
                 if (rec[t] >= 0) {
                     f32x4 dzv;
+                    const f32x4 zq = finish_vec4(zv[t], bf16);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float z = zv[t][r], d = dcur[t][r];
+                        const float z = zq[r], d = dcur[t][r];
                         float dz = d;
                         if (!(z > 0.f)) {
                             dz = alpha * d;
