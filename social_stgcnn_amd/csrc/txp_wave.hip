@@ -199,6 +199,14 @@ __device__ __forceinline__ void wave_dma(const float *__restrict__ src, float *l
     }
 }
 
+// "Every vector-memory operation issued so far has completed", stated where the compiler can see it (an S_WAITCNT it
+// models).  vmcnt counts loads AND stores in order; wherever a register MAY still be waiting for a load on some path of
+// the control-flow graph (a tile loop whose iterations are guarded by runtime tile counts is enough), the compiler puts
+// s_waitcnt vmcnt(0) in front of its use -- which also waits for the acknowledgement of every store issued since: one
+// HBM round trip per tile.  Draining once, right after the loads and before the guarded code, leaves nothing pending,
+// and the tiles' stores are fire-and-forget again.  (Found in the ISA, not in a counter: DESIGN 5.2.)
+__device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), expcnt / lgkmcnt free
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
@@ -443,13 +451,6 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
 // (<= 10 tiles for V_n <= 32).  The st_gcn block (column mode) hands its outputs over in registers as well.
 constexpr int kF6Tiles = 10, kF6Slots = 7;
 
-// "Every vector-memory operation issued so far has completed", stated where the compiler can see it (an S_WAITCNT it
-// models).  vmcnt counts loads AND stores in order; wherever a register MAY still be waiting for a load on some path of
-// the control-flow graph (a tile loop whose iterations are guarded by runtime tile counts is enough), the compiler puts
-// s_waitcnt vmcnt(0) in front of its use -- which also waits for the acknowledgement of every store issued since: one
-// HBM round trip per tile.  Draining once, right after the loads and before the guarded code, leaves nothing pending,
-// and the tiles' stores are fire-and-forget again.  (F 72 -> see DESIGN 5.2; found in the ISA, not in a counter.)
-__device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), expcnt / lgkmcnt free
 __host__ __device__ inline int fwd6_region_floats(int v) { return (cv::image_bytes(v, kF6Slots) / 4 + 3) & ~3; }
 
 __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const float *__restrict__ params,
