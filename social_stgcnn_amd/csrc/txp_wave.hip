@@ -453,6 +453,7 @@ constexpr int kF6Tiles = 10, kF6Slots = 7;
 
 __host__ __device__ inline int fwd6_region_floats(int v) { return (cv::image_bytes(v, kF6Slots) / 4 + 3) & ~3; }
 
+template <bool BF>                 // BF: bf16 storage of the saved planes / pre-activations (STG_OPT_BF16_STORE)
 __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const float *__restrict__ params,
                                                  const float *blk_params, const float *blk_buffers, int n, float *region,
                                                  ptab_t *ptab) {
@@ -473,7 +474,7 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
     float *statn = a.stats ? a.stats + (int64_t)n * L.stat_floats : nullptr;
     unsigned char *img = reinterpret_cast<unsigned char *>(region);
     const cv::LaneGeom lg = cv::lane_geom(vi, kF6Slots);
-    const bool bf16 = (L.flags & STG_OPT_BF16_STORE) != 0;        // bf16 storage of the saved planes / pre-activations
+    constexpr bool bf16 = BF;
     const int SWs = save_sw(vi, bf16), VWs = save_vw(vi, bf16);   // row strides (positions) of the saved arrays
 
     // ---- st_gcn block (model.py:145-155), column mode: lane = pedestrian; zeroes the image, builds the position table
@@ -571,7 +572,7 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
     }
 }
 
-template <int WPB>
+template <int WPB, bool BF>
 __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_fwd_x6_kernel(
     const TxpFwdArgs a, const float *__restrict__ params, const float *__restrict__ buffers) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
         const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
-        txp_fwd_scene_x6(a, params, blk_p, blk_b, n, region, ptab);
+        txp_fwd_scene_x6<BF>(a, params, blk_p, blk_b, n, region, ptab);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1045,6 +1046,7 @@ __host__ __device__ inline int bwd6_region_floats(int v) {
     return ((img > tail ? img : tail) + 3) & ~3;
 }
 
+template <bool BF>                 // BF: bf16 storage of z_l (read) and dz_l (written)
 __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const float *blk_params, int n, float *region,
                                                  ptab_t *ptab, float *tot) {
     const ModelLayout &L = a.lay;
@@ -1063,7 +1065,7 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
     const float *dyn = a.dy + (int64_t)n * (C * P) * V;
     unsigned char *img = reinterpret_cast<unsigned char *>(region);
     const cv::LaneGeom lg = cv::lane_geom(vi, kX6Slots);
-    const bool bf16 = (L.flags & STG_OPT_BF16_STORE) != 0;        // bf16 storage of z_l (read) and dz_l (written)
+    constexpr bool bf16 = BF;
     const int VWs = save_vw(vi, bf16);                             // row stride (positions) of the saved z_l / dz_l
     // vector index of the lane's quad of tile t in those arrays (fp32: rows of vi positions, i.e. (16 t + n) * 3 + kq)
     auto quad_of = [&](int t) -> int {
@@ -1255,7 +1257,7 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
     txp_bwd_block_tail<true>(a, blk_params, n, vi, region, nullptr, ptab, tot, slope_row, true);
 }
 
-template <int WPB>
+template <int WPB, bool BF>
 __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_bwd_x6_kernel(
     const TxpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1274,7 +1276,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
         const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
-        txp_bwd_scene_x6(a, blk_p, n, region, ptab, tot);
+        txp_bwd_scene_x6<BF>(a, blk_p, n, region, ptab, tot);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1463,17 +1465,19 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
     TxpFwdArgs a = a0;
     if (a.wpf && txp_fwd_x6_fits(a.lay, a.V)) {
         const size_t per_wave = (size_t)(fwd6_region_floats(a.Vl) + ptab_floats(a.Vl)) * sizeof(float);
-        const int wpb = wave_wpb(per_wave);
+        const int wpb = wave_wpb(per_wave) == 8 ? 8 : 4;     // (the 18 KB images of V <= 32 always fit four waves)
         const size_t lds = per_wave * wpb + wave_param_floats(a.lay) * sizeof(float);
         const dim3 grid(wave_grid(lds, wpb, a.N));
-#define STG_LX(W)                                                                                             \
+        const bool bf = (a.lay.flags & STG_OPT_BF16_STORE) != 0;
+#define STG_LX(W, B)                                                                                          \
     do {                                                                                                      \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_fwd_x6_kernel<W>),            \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_fwd_x6_kernel<W, B>),         \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
         if (e_ != hipSuccess) return hip_fail(e_, "txp_fwd_x6: hipFuncSetAttribute");                         \
-        hipLaunchKernelGGL(txp_fwd_x6_kernel<W>, grid, dim3(W * 64), lds, st, a, a.params, a.buffers);        \
+        hipLaunchKernelGGL((txp_fwd_x6_kernel<W, B>), grid, dim3(W * 64), lds, st, a, a.params, a.buffers);   \
     } while (0)
-        if (wpb == 8) STG_LX(8); else if (wpb == 4) STG_LX(4); else if (wpb == 2) STG_LX(2); else STG_LX(1);
+        if (wpb == 8) { if (bf) STG_LX(8, true); else STG_LX(8, false); }
+        else { if (bf) STG_LX(4, true); else STG_LX(4, false); }
 #undef STG_LX
         STG_LAUNCH_CHECK("txp_fwd_x6");
         return STG_OK;
@@ -1513,17 +1517,19 @@ int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {
     TxpBwdArgs a = a0;
     if (a.wp && txp_bwd_x6_fits(a.lay, a.V)) {
         const size_t per_wave = (size_t)(bwd6_region_floats(a.Vl) + bwd_ptab_floats(a.Vl)) * sizeof(float);
-        const int wpb = wave_wpb(per_wave);
+        const int wpb = wave_wpb(per_wave) == 8 ? 8 : 4;
         const size_t lds = per_wave * wpb + wave_param_floats(a.lay) * sizeof(float);
         const dim3 grid(wave_grid(lds, wpb, a.N));
-#define STG_LX(W)                                                                                             \
+        const bool bf = (a.lay.flags & STG_OPT_BF16_STORE) != 0;
+#define STG_LX(W, B)                                                                                          \
     do {                                                                                                      \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_bwd_x6_kernel<W>),            \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_bwd_x6_kernel<W, B>),         \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
         if (e_ != hipSuccess) return hip_fail(e_, "txp_bwd_x6: hipFuncSetAttribute");                         \
-        hipLaunchKernelGGL((txp_bwd_x6_kernel<W>), grid, dim3(W * 64), lds, st, a);                           \
+        hipLaunchKernelGGL((txp_bwd_x6_kernel<W, B>), grid, dim3(W * 64), lds, st, a);                        \
     } while (0)
-        if (wpb == 8) STG_LX(8); else if (wpb == 4) STG_LX(4); else if (wpb == 2) STG_LX(2); else STG_LX(1);
+        if (wpb == 8) { if (bf) STG_LX(8, true); else STG_LX(8, false); }
+        else { if (bf) STG_LX(4, true); else STG_LX(4, false); }
 #undef STG_LX
         STG_LAUNCH_CHECK("txp_bwd_x6");
         return STG_OK;
