@@ -180,14 +180,26 @@ struct Tile {
 };
 
 // IN0 = row slot of interior row 0 of the INPUT image (3: high image, 1: low image)
+// the (row << 8 | column) code of the lane's position of a tile (position 0 past the scene's end), and the tile built from
+// a code fetched earlier: the tile loops fetch tile t+1's code before tile t's operand reads, so that the table's LDS
+// latency is not paid in front of every tile's address arithmetic
+__device__ __forceinline__ unsigned tile_code(int tile, const ptab_t *ptab, int npos) {
+    const int p = tile * 16 + (int)(threadIdx.x & 15);
+    return ptab[p < npos ? p : 0];
+}
+template <int IN0>
+__device__ __forceinline__ Tile tile_from(int tile, unsigned hw, int npos, const LaneGeom &lg, int vi);
 template <int IN0>
 __device__ __forceinline__ Tile tile_of(int tile, const ptab_t *ptab, int npos, const LaneGeom &lg, int vi) {
+    return tile_from<IN0>(tile, tile_code(tile, ptab, npos), npos, lg, vi);
+}
+template <int IN0>
+__device__ __forceinline__ Tile tile_from(int tile, unsigned hw, int npos, const LaneGeom &lg, int vi) {
     const int n = threadIdx.x & 15, kg = (threadIdx.x & 63) >> 4;
     Tile t;
     const int p = tile * 16 + n;
     t.ok = p < npos;
     t.pos = t.ok ? p : 0;
-    const unsigned hw = ptab[t.pos];
     t.h = (int)(hw >> 8);
     t.w = (int)(hw & 0xffu);
     const int SW = sw(vi);

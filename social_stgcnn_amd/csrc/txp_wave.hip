@@ -529,10 +529,12 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
         // the layer's operands and bias have landed before the first guarded tile: no vmcnt wait inside the tile loop
         asm volatile("" ::"v"(w[0]), "v"(w[cv::kWpVecs - 1]), "v"(binit), "v"(alpha) : "memory");
         vm_drain();
+        unsigned code = cv::tile_code(0, ptab, npos);
 #pragma unroll
         for (int t = 0; t < kF6Tiles; ++t) {
             if (t < ntiles) {
-                const cv::Tile tl = cv::tile_of<1>(t, ptab, npos, lg, vi);
+                const cv::Tile tl = cv::tile_from<1>(t, code, npos, lg, vi);
+                if (t + 1 < kF6Tiles) code = cv::tile_code(t + 1, ptab, npos);      // (in flight behind this tile's reads)
                 cv::BHalf b;
                 f32x4 z = binit;
                 cv::load_b_half<0>(lds_base, tl, b);
@@ -1222,10 +1224,12 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
             const unsigned lds_base = (unsigned)(uintptr_t)img;
             const bool keep = l != L.L && l != 0;       // d(a_l) += d(a_{l+1}) (a_{l+1} = prelu(z_l) + a_l for 1 <= l < L)
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            unsigned code = cv::tile_code(0, ptab, npos);
 #pragma unroll
             for (int t = 0; t < kX6Tiles; ++t) {
                 if (t < ntiles) {
-                    const cv::Tile tl = cv::tile_of<1>(t, ptab, npos, lg, vi);
+                    const cv::Tile tl = cv::tile_from<1>(t, code, npos, lg, vi);
+                    if (t + 1 < kX6Tiles) code = cv::tile_code(t + 1, ptab, npos);  // (in flight behind this tile's reads)
                     // two half-tiles through ONE 32-register operand set (96 weight + 40 gradient registers are live);
                     // each half's reads and their wait are one asm statement, the SIMD's other wave covers the latency
                     cv::BHalf b;
