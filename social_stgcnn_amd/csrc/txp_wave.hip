@@ -549,7 +549,7 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
                     } else {
                         f32x4 v4;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v4[r] = (z[r] > 0.f ? z[r] : alpha * z[r]) + (l > 0 ? av[t][r] : 0.f);
+                        for (int r = 0; r < 4; ++r) v4[r] = (z[r] > 0.f ? z[r] : alpha * z[r]) + av[t][r];   // (av = 0 at l = 0)
                         av[t] = v4;
                         if (zs) {
                             store_vec4(zs, (tl.h * VWs + tl.w) * 3 + kq, z, bf16);
@@ -562,11 +562,14 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
         if (is_out) break;
         // every tile has read a_l: a_{l+1} replaces it in the image
         __builtin_amdgcn_wave_barrier();
+        unsigned codes[kF6Tiles];                      // (all ten table reads in flight: the weight registers are dead here)
+#pragma unroll
+        for (int t = 0; t < kF6Tiles; ++t) codes[t] = cv::tile_code(t, ptab, npos);
 #pragma unroll
         for (int t = 0; t < kF6Tiles; ++t) {
             const int p = 16 * t + nq;
             if (p < npos && kq < 3) {
-                const unsigned hw = ptab[p];
+                const unsigned hw = codes[t];
                 cv::put4(img, (unsigned)(cv::pos_off(vi, 1 + (int)(hw >> 8), (int)(hw & 0xffu)) + 8 * kq), lg.PL, av[t]);
             }
         }
@@ -1069,11 +1072,15 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
     const cv::LaneGeom lg = cv::lane_geom(vi, kX6Slots);
     constexpr bool bf16 = BF;
     const int VWs = save_vw(vi, bf16);                             // row stride (positions) of the saved z_l / dz_l
-    // vector index of the lane's quad of tile t in those arrays (fp32: rows of vi positions, i.e. (16 t + n) * 3 + kq)
-    auto quad_of = [&](int t) -> int {
+    // From ONE read of the position table: the vector index of the lane's quad of tile t in those arrays (fp32: rows of vi
+    // positions, i.e. (16 t + n) * 3 + kq) and the byte offset of its record quad in the image (interior row 0 = slot 1;
+    // -1 past the scene's last position)
+    auto tile_slots = [&](int t, int &rec, int &quad) {
         const int p = 16 * t + nq;
         const unsigned hw = ptab[p < npos ? p : 0];
-        return ((int)(hw >> 8) * VWs + (int)(hw & 0xffu)) * 3 + kq;
+        const int h = (int)(hw >> 8), w = (int)(hw & 0xffu);
+        quad = (h * VWs + w) * 3 + kq;
+        rec = (p < npos && kq < 3) ? cv::pos_off(vi, 1 + h, w) + 8 * kq : -1;
     };
     {
         uint4 *z4 = reinterpret_cast<uint4 *>(img);
@@ -1081,13 +1088,6 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
     }
     build_ptab(ptab, vi);
     __builtin_amdgcn_wave_barrier();
-    // this lane's position of every tile: byte offset of its record quad in the image (interior row 0 = slot 1), -1 past
-    // the scene's last position
-    auto rec_of = [&](int t) -> int {
-        const int p = 16 * t + nq;
-        const unsigned hw = ptab[p < npos ? p : 0];
-        return (p < npos && kq < 3) ? cv::pos_off(vi, 1 + (int)(hw >> 8), (int)(hw & 0xffu)) + 8 * kq : -1;
-    };
     f32x4 dcur[kX6Tiles];
 #pragma unroll
     for (int t = 0; t < kX6Tiles; ++t) dcur[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1164,12 +1164,14 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
                 for (int e = lane; e < (2 * lg.PL + 128) >> 4; e += 64) z4[e] = make_uint4(0u, 0u, 0u, 0u);
             }
             __builtin_amdgcn_wave_barrier();
+            int rec[kX6Tiles], qv[kX6Tiles];           // (the table reads of all ten tiles in flight together)
+#pragma unroll
+            for (int t = 0; t < kX6Tiles; ++t) tile_slots(t, rec[t], qv[t]);
 #pragma unroll
             for (int t = 0; t < kX6Tiles; ++t) {
-                const int rc_ = rec_of(t);
-                if (rc_ >= 0) {
-                    cv::put4(img, (unsigned)rc_, lg.PL, qd[t]);
-                    store_vec4(dzo, quad_of(t), qd[t], bf16);
+                if (rec[t] >= 0) {
+                    cv::put4(img, (unsigned)rec[t], lg.PL, qd[t]);
+                    store_vec4(dzo, qv[t], qd[t], bf16);
                 }
             }
         } else {
@@ -1183,12 +1185,12 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
             // never-awaited "touch" load into a dead register is not an option either -- the register is reused
             // while the load is in flight and the late write-back corrupts its new owner.)
             f32x4 zv[kX6Tiles];
-            int rec[kX6Tiles];
+            int rec[kX6Tiles], qv[kX6Tiles];
 #pragma unroll
-            for (int t = 0; t < kX6Tiles; ++t) rec[t] = rec_of(t);
+            for (int t = 0; t < kX6Tiles; ++t) tile_slots(t, rec[t], qv[t]);
 #pragma unroll
             for (int t = 0; t < kX6Tiles; ++t)
-                zv[t] = rec[t] >= 0 ? load_vec4_raw(zl, quad_of(t), bf16) : f32x4{1.f, 1.f, 1.f, 1.f};
+                zv[t] = rec[t] >= 0 ? load_vec4_raw(zl, qv[t], bf16) : f32x4{1.f, 1.f, 1.f, 1.f};
             // all ten have landed before the first guarded tile: the tiles' dz stores are not waited for (vm_drain)
             asm volatile("" ::"v"(zv[0]), "v"(zv[1]), "v"(zv[2]), "v"(zv[3]), "v"(zv[4]), "v"(zv[5]), "v"(zv[6]), "v"(zv[7]),
                          "v"(zv[8]), "v"(zv[9]), "v"(alpha)
@@ -1210,7 +1212,7 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
                         dzv[r] = dz;
                     }
                     cv::put4(img, (unsigned)rec[t], lg.PL, dzv);
-                    store_vec4(dzo, quad_of(t), dzv, bf16);
+                    store_vec4(dzo, qv[t], dzv, bf16);
                 }
             }
             slope_acc = wave_sum(slope_acc);
