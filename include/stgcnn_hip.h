@@ -125,7 +125,7 @@ typedef struct {
                                * where the default uses v_mfma_f32_16x16x32_bf16 with exact three-piece operands (V <= 32, fp32
                                * storage): same accuracy class, for A/B measurements                                            */
 #define STG_OPT_WAVE_PATH 4   /* keep the wave-per-scene kernels for small batches too (default: batches of fewer than  */
-                              /* 513 scenes of <= 40 pedestrians run the workgroup kernels, several waves per scene)     */
+                              /* 288 scenes of <= 40 pedestrians run the workgroup kernels, several waves per scene)     */
 
 int64_t stg_model_param_count(const stg_model_desc *d);
 int64_t stg_model_buffer_count(const stg_model_desc *d);

@@ -1424,7 +1424,7 @@ bool txp_wave_fits(const ModelLayout &L, int V) {
     return fwd <= 48 * 1024;        // at least three waves per CU
 }
 
-constexpr int kSmallBatch = 513;      // up to 512 scenes: 4 waves per scene fill the 2048 wave slots in one round (640: 2.9 vs ~3.7 M/s)
+constexpr int kSmallBatch = 288;      // measured: 256 scenes 1.89 (workgroup kernels) vs 1.79 M/s (a wave per scene), 320 scenes 2.10 vs 2.19
 
 bool use_wave_path(const ModelLayout &L, int N, int V, int *wg_waves) {
     if (wg_waves) *wg_waves = L.wg_waves;

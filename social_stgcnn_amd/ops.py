@@ -179,7 +179,7 @@ class FlatPack:
 #   wg_path     run the workgroup-per-scene kernels even where the wave-per-scene path fits (tests cover both)
 #   split_bf16  TXP input-gradient GEMMs on bf16 MFMAs with hi/lo-split operands (opt-in, fp32 in / out)
 #   wg_waves    0 = auto, or 1 / 2 / 4 / 8 waves per scene in the workgroup-per-scene kernels
-#   wave_path   keep the wave-per-scene kernels for small batches too (default: batches of up to 512 scenes of <= 40
+#   wave_path   keep the wave-per-scene kernels for small batches too (default: batches of fewer than 288 scenes of <= 40
 #               pedestrians run the workgroup kernels with 4 or 8 waves per scene -- one wave per scene would leave
 #               most of the chip's wave slots empty)
 #   bf16_store  bf16 storage of the saved TXP activations and of the dz hand-off (STG_OPT_BF16_STORE): fp32 forward
