@@ -1223,6 +1223,8 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
         if (!STG_SKIP(a, 1024)) {
             cv::u32x4 w[cv::kWpVecs];
             cv::load_wp(a.wp + (int64_t)l * cv::kWpDwords, w);
+            asm volatile("" ::"v"(w[0]), "v"(w[cv::kWpVecs - 1]) : "memory");
+            vm_drain();                                 // (no per-operand waits in front of every guarded tile)
             const unsigned lds_base = (unsigned)(uintptr_t)img;
             const bool keep = l != L.L && l != 0;       // d(a_l) += d(a_{l+1}) (a_{l+1} = prelu(z_l) + a_l for 1 <= l < L)
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
