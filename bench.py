@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-extras", action="store_true", help="skip the pipeline / stand-alone kernel / roofline legs")
+    ap.add_argument("--kernels-only", action="store_true",
+                    help="of the extra legs keep only the per-kernel device times (roofline); no pipeline / epoch / HBM kernels")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
@@ -479,7 +481,7 @@ def main():
             _ = vmean
 
         # ---- pipeline: adjacency build inside the step ---------------------------------------------------------
-        if not args.no_graph:
+        if not args.no_graph and not args.kernels_only:
             psteps = [trainer.capture(d["x"], d["adj"], d["tgt"], d["peds"], weights,
                                       pre=(lambda d=d: ops.adj_build(d["rel"], d["peds"], out=(d["nodes"], d["adj"]))))
                       for d in dsets]
@@ -493,7 +495,7 @@ def main():
                                    "unit": "scene-windows/s"}
 
     # ---- real-data epochs from the device-resident dataset (N1): gather by device index inside the captured step ----
-    if args.dataset == "eth-train" and not args.no_extras and not args.no_graph and world == 1:
+    if args.dataset == "eth-train" and not args.no_extras and not args.kernels_only and not args.no_graph and world == 1:
         from social_stgcnn_amd import data
         from social_stgcnn_amd.dataset import DeviceWindows, EpochRunner
         win = data.load_windows(os.path.join(ROOT, "tests", "golden", "data", "eth_train"), T_OBS, T_PRED, 1,
@@ -517,7 +519,7 @@ def main():
                         "unit": "scene-windows/s", "last_epoch_loss": float(last)}
 
     # ---- stand-alone HBM kernels on a working set beyond the Infinity Cache (rank 0) --------------------------------
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and not args.no_extras and not args.kernels_only:
         vb = 32
         nb = 16384                                            # adjacency: 16384 x 8 x 32 x 32 x 4 B = 537 MB > 256 MiB
         rel_b, _ = synth_scenes(256, vb, 7)

@@ -90,8 +90,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // K independent wave sums at once: every DPP stage is applied to all K values before the next stage, so the
 // dependent-DPP wait states of one chain are filled by the other chains (a lone wave_sum costs ~350 cycles of
 // nops and readlane hazards at two waves per SIMD; K at once ~30 cycles per value).
+// the DPP stages alone: lane 63 ends up with the K wave totals (the other lanes hold partial sums)
 template <int K>
-__device__ __forceinline__ void wave_sum_n(float (&v)[K]) {
+__device__ __forceinline__ void wave_sum_to_last(float (&v)[K]) {
 #define STG_DPP_STAGE(ctrl, row_mask)                                                                                \
     _Pragma("unroll") for (int k = 0; k < K; ++k)                                                                    \
         v[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), (ctrl), (row_mask), 0xf, false))
@@ -102,6 +103,10 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[K]) {
     STG_DPP_STAGE(0x142, 0xa);
     STG_DPP_STAGE(0x143, 0xc);
 #undef STG_DPP_STAGE
+}
+template <int K>
+__device__ __forceinline__ void wave_sum_n(float (&v)[K]) {
+    wave_sum_to_last<K>(v);
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
 }

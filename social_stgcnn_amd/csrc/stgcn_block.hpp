@@ -8,6 +8,7 @@
 // N = 1, train.py:173-177) through DPP wave reductions (+ LDS across waves in workgroup mode).
 #pragma once
 #include "model_common.hpp"
+#include "scene_team.hpp"
 
 namespace stg {
 
@@ -460,19 +461,25 @@ __device__ __forceinline__ void stgcn_block_fwd(const Args &a, const float *__re
 // HALF (V_n <= 32, register hand-over only): lane = (pedestrian, time half) -- lanes 0..31 own t = 0..3, lanes 32..63
 // t = 4..7; the temporal conv's taps across the half boundary come from the partner lane (lane ^ 32), and `regs_out`
 // receives the 20 outputs f = 20*half .. 20*half+19 of the pedestrian (plane channels 4*half .. 4*half+3 of its 5 rows).
-template <bool HALF = false, typename Args>
+// CK (scene_team.hpp): SoloScene -- the wave owns the scene -- or TeamScene: the wave owns the column chunk
+// [ck.w0(), ck.w0() + ck.wc()) of a scene shared by ck.nch() waves (HALF only; the scene-wide BatchNorm sums are
+// exchanged through LDS, `plane_base` is the team's shared image and is zeroed by all of them, `qtab` is the wave's own
+// table of its chunk's positions).
+template <bool HALF, typename Args, typename CK>
 __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float *P_, const float *B_, const BlockLayout &b,
                                                      int n, int vi, float *wsn, float *statn, const float *pre_ax,
                                                      const float *pre_cs, float *plane, int plane_sc, float *plane_base,
-                                                     int plane_zero_f4, ptab_t *qtab, float *regs_out = nullptr) {
+                                                     int plane_zero_f4, ptab_t *qtab, float *regs_out, const CK &ck) {
     // regs_out (a register array of C*T floats in the caller): the outputs of pedestrian w, flat index f = c*T+t, are
     // handed back instead of written to `plane` (the exact-bf16 forward splits and stores them itself)
     constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, CIN = Cfg::CIN0;
     [[maybe_unused]] constexpr int WAVES = 0;          // (diagnostic stamps)
     constexpr int TL = HALF ? T / 2 : T;               // time steps of a lane
+    static_assert(HALF || !CK::kTeam, "a team of waves shares a scene in (pedestrian, time half) mode only");
     const int lane = threadIdx.x & 63, V = a.V;
-    const int w = HALF ? lane & 31 : lane, hh = HALF ? lane >> 5 : 0, toff = TL * hh;
-    const bool act = w < vi, lane0 = lane == 0;
+    const int wl = HALF ? lane & 31 : lane, hh = HALF ? lane >> 5 : 0, toff = TL * hh;
+    const int w = ck.w0() + wl;                        // the lane's pedestrian
+    const bool act = wl < ck.wc(), lane0 = lane == 0 && ck.lead();
     const float fact = act ? 1.f : 0.f;
     const int cnt = T * vi;
     const bool train = a.lay.bn_mode == 1;
@@ -497,10 +504,11 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
         // at the end; the scene's position table
         {
             float4 *z4 = reinterpret_cast<float4 *>(plane_base);
-            for (int e = lane; e < plane_zero_f4; e += 64) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int p = lane; p < T * vi; p += 64) {
-                const int h = p / vi;
-                qtab[p] = (ptab_t)((h << 8) | (p - h * vi));
+            for (int e = lane + 64 * ck.ci(); e < plane_zero_f4; e += 64 * ck.nch()) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int wcw = ck.wc();
+            for (int p = lane; p < T * wcw; p += 64) {
+                const int h = p / wcw;
+                qtab[p] = (ptab_t)((h << 8) | (ck.w0() + p - h * wcw));
             }
         }
         // ---- gcn 1x1 conv on the aggregated input (model.py:66-67) --------------------------------------
@@ -531,7 +539,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
 #pragma unroll
             for (int t = 0; t < TL; ++t) s1[c] += g[c][t];            // (inactive lanes hold zeros)
         }
-        wave_sum_n<C>(s1);
+        ck.template sum<C>(s1, kXrF_s1);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             m1[c] = s1[c] * inv_cnt;
@@ -543,7 +551,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
             }
             s2[c] = s * fact;
         }
-        wave_sum_n<C>(s2);
+        ck.template sum<C>(s2, kXrF_s2);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             r1[c] = 1.0f / sqrtf(s2[c] * inv_cnt + eps);
@@ -640,7 +648,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
             sm2[c] = s * fact;
             sm2[C + c] = sr * fact;
         }
-        wave_sum_n<2 * C>(sm2);
+        ck.template sum<2 * C>(sm2, kXrF_sm2);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             m2[c] = sm2[c] * inv_cnt;
@@ -662,7 +670,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
             sv2[c] = v * fact;
             sv2[C + c] = vr * fact;
         }
-        wave_sum_n<2 * C>(sv2);
+        ck.template sum<2 * C>(sv2, kXrF_sv2);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             r2[c] = 1.0f / sqrtf(sv2[c] * inv_cnt + eps);
@@ -701,7 +709,7 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
     }
     STG_BLK_STAMP(14);
     // ---- BN (tcn.3) + residual + PReLU (model.py:150-153) -> the TXP plane -------------------------------
-    __builtin_amdgcn_wave_barrier();                  // (the image is zero before its interior is written)
+    ck.sync();                                        // (the image is zero before its interior is written)
     const float ao = P_[b.prelu_o];
     const int SW = txp_sw(vi);
     float *pw = plane + (w + 1);
@@ -750,6 +758,15 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
     }
     __builtin_amdgcn_wave_barrier();
 }
+// the wave owns the scene
+template <bool HALF = false, typename Args>
+__device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float *P_, const float *B_, const BlockLayout &b,
+                                                     int n, int vi, float *wsn, float *statn, const float *pre_ax,
+                                                     const float *pre_cs, float *plane, int plane_sc, float *plane_base,
+                                                     int plane_zero_f4, ptab_t *qtab, float *regs_out = nullptr) {
+    stgcn_block_fwd_cols<HALF>(a, P_, B_, b, n, vi, wsn, statn, pre_ax, pre_cs, plane, plane_sc, plane_base, plane_zero_f4,
+                               qtab, regs_out, SoloScene{vi});
+}
 
 // ------------------------------------------------------------------------------------------
 // backward, column mode (wave-per-scene kernels, vi <= 64, first-block shape, no input gradient): lane = pedestrian, the
@@ -762,14 +779,24 @@ __device__ __forceinline__ void stgcn_block_fwd_cols(const Args &a, const float 
 // HALF (vi <= 32): lane = (pedestrian, time half) -- lanes 0..31 own t = 0..3, lanes 32..63 t = 4..7 -- so that a crowd of
 // <= 32 uses every lane and the per-lane arrays halve; the temporal conv's two taps across the half boundary come from
 // the partner lane (lane ^ 32).
-template <bool HALF, typename Args>
+// CK: SoloScene, or TeamScene -- the wave owns one column chunk of a scene shared by several waves (HALF only): the two
+// reductions the BatchNorm backward goes on with are scene-wide sums (exchanged through LDS), the parameter gradients are
+// parked per wave (scene_team.hpp) -- the caller adds the parked rows into the scene's row afterwards.
+template <bool HALF, typename Args, typename CK>
 __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float *P_, const BlockLayout &b, int n, int vi,
-                                                     const float *D, float *row, const float *wsn) {
+                                                     const float *D, float *row, const float *wsn, const CK &ck) {
     constexpr int C = Cfg::C, T = Cfg::T, KT = Cfg::KT, CIN = Cfg::CIN0;
     constexpr int TL = HALF ? T / 2 : T;               // time steps of a lane
+    static_assert(HALF || !CK::kTeam, "a team of waves shares a scene in (pedestrian, time half) mode only");
     const int lane = threadIdx.x & 63, V = a.V;
-    const int w = HALF ? lane & 31 : lane, hh = HALF ? lane >> 5 : 0, toff = TL * hh;
-    const bool act = w < vi, lane0 = lane == 0;
+    const int wl = HALF ? lane & 31 : lane, hh = HALF ? lane >> 5 : 0, toff = TL * hh;
+    const int w = ck.w0() + wl;                        // the lane's pedestrian
+    const bool act = wl < ck.wc(), lane0 = lane == 0 && ck.lead();
+    // where the gradients go: the scene's row (a wave that owns its scene), or this wave's parked row in LDS (a team: the
+    // leading wave adds the rows at the end of the scene).  Totals of scene-wide sums (ck.sum) are written by lane0,
+    // totals of per-wave sums (ck.reduce) by ck.writer().
+    row = ck.row(row);
+    const bool wr = ck.writer();
     const bool train = a.lay.bn_mode == 1, res2 = b.residual == 2;
     const float inv_cnt = 1.0f / (float)(T * vi);
     const float *wsa = wsn + a.lay.ws_hdr_floats;
@@ -840,7 +867,7 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
             s1[2 * C + c] = fmaf(du, xr, s1[2 * C + c]);
         }
     }
-    wave_sum_n<3 * C + 1>(s1);
+    ck.template sum<3 * C + 1>(s1, kXrB_s1);
     if (lane0) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -884,8 +911,8 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
             }
         }
         if (res2) {
-            wave_sum_n<C * CIN + C>(s2);
-            if (lane0) {
+            ck.template reduce<C * CIN + C>(s2);
+            if (wr) {
 #pragma unroll
                 for (int k = 0; k < C * CIN; ++k) row[b.res_w + k] = s2[k];
 #pragma unroll
@@ -931,8 +958,8 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
 #pragma unroll
                 for (int ci = 0; ci < C; ++ci) sw[c * C + ci] = fmaf(h2[c][t], he[ci][t + dt], sw[c * C + ci]);
         }
-        wave_sum_n<C * C>(sw);
-        if (lane0) {
+        ck.template reduce<C * C>(sw);
+        if (wr) {
 #pragma unroll
             for (int k = 0; k < C * C; ++k) row[b.tcn_w + k * KT + dt] = sw[k];
         }
@@ -996,7 +1023,7 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
             }
         }
     }
-    wave_sum_n<3 * C + 1>(s3);
+    ck.template sum<3 * C + 1>(s3, kXrB_s3);
     if (lane0) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -1023,14 +1050,20 @@ __device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float 
                 s4[C * CIN + c] = fmaf(dg, cs[t], s4[C * CIN + c]);
             }
         }
-        wave_sum_n<C * CIN + C>(s4);
-        if (lane0) {
+        ck.template reduce<C * CIN + C>(s4);
+        if (wr) {
 #pragma unroll
             for (int k = 0; k < C * CIN; ++k) row[b.gcn_w + k] = s4[k];
 #pragma unroll
             for (int c = 0; c < C; ++c) row[b.gcn_b + c] = s4[C * CIN + c];
         }
     }
+}
+// the wave owns the scene
+template <bool HALF, typename Args>
+__device__ __forceinline__ void stgcn_block_bwd_cols(const Args &a, const float *P_, const BlockLayout &b, int n, int vi,
+                                                     const float *D, float *row, const float *wsn) {
+    stgcn_block_bwd_cols<HALF>(a, P_, b, n, vi, D, row, wsn, SoloScene{vi});
 }
 
 // ------------------------------------------------------------------------------------------

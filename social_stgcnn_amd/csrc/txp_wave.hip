@@ -94,6 +94,16 @@ __device__ __forceinline__ void build_ptab(ptab_t *ptab, int vi) {
         ptab[p] = (ptab_t)((h << 8) | (p - h * vi));
     }
 }
+// the same for a wave that owns the column chunk [w0, w0 + wc) of a scene: position p of the chunk is (row p / wc, column
+// w0 + p % wc) of the scene
+__device__ __forceinline__ void build_ptab(ptab_t *ptab, int w0, int wc) {
+    const int lane = threadIdx.x & 63;
+    if (wc <= 0 && lane == 0) ptab[0] = 0;            // (an empty chunk: entry 0 is still read, never used)
+    for (int p = lane; p < T * wc; p += 64) {
+        const int h = p / wc;
+        ptab[p] = (ptab_t)((h << 8) | (w0 + p - h * wc));
+    }
+}
 
 
 __device__ __forceinline__ TileGeom tile_geom(int tile0, const ptab_t *ptab, int npos) {
@@ -453,22 +463,23 @@ constexpr int kF6Tiles = 10, kF6Slots = 7;
 
 __host__ __device__ inline int fwd6_region_floats(int v) { return (cv::image_bytes(v, kF6Slots) / 4 + 3) & ~3; }
 
-template <bool BF>                 // BF: bf16 storage of the saved planes / pre-activations (STG_OPT_BF16_STORE)
+// CK (scene_team.hpp): SoloScene -- this wave owns the scene, `region` / `ptab` are its own -- or TeamScene: the wave owns
+// the column chunk [ck.w0(), ck.w0() + ck.wc()) of a scene that ck.nch() waves share (`region` = the team's image, `ptab` =
+// this wave's table of its chunk's positions); `vi` = pedestrians of the scene.
+template <bool BF, typename CK>    // BF: bf16 storage of the saved planes / pre-activations (STG_OPT_BF16_STORE)
 __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const float *__restrict__ params,
-                                                 const float *blk_params, const float *blk_buffers, int n, float *region,
-                                                 ptab_t *ptab) {
+                                                 const float *blk_params, const float *blk_buffers, int n, int vi,
+                                                 float *region, ptab_t *ptab, const CK &ck) {
     const ModelLayout &L = a.lay;
     const int V = a.V, lane = threadIdx.x & 63, nq = lane & 15, kq = lane >> 4;
-    int vi = a.num_peds ? a.num_peds[n] : V;
-    vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
     float *yn = a.y + (int64_t)n * (C * P) * V;
     if (vi < V)                                        // padded pedestrian slots of the output are zeros
-        for (int e = lane; e < C * P * (V - vi); e += 64) {
+        for (int e = lane + 64 * ck.ci(); e < C * P * (V - vi); e += 64 * ck.nch()) {
             const int r = e / (V - vi), w = vi + (e - r * (V - vi));
             yn[(int64_t)r * V + w] = 0.f;
         }
     if (vi == 0) return;
-    const int npos = C * vi, ntiles = (npos + 15) >> 4;
+    const int npos = C * ck.wc(), ntiles = (npos + 15) >> 4;      // this wave's positions: (row, its columns)
     const float *Pm = params;
     float *wsn = a.ws ? a.ws + n * a.ws_stride : nullptr;
     float *statn = a.stats ? a.stats + (int64_t)n * L.stat_floats : nullptr;
@@ -483,13 +494,14 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
         float sv[C * T / 2];
         const float *agn = a.agg + n * a.agg_stride;
         stgcn_block_fwd_cols<true>(a, blk_params, blk_buffers, L.blk[0], n, vi, wsn, statn, agn + a.agg_ax, agn + a.agg_cs,
-                                   nullptr, 0, region, cv::image_bytes(vi, kF6Slots) >> 4, ptab, sv);
+                                   nullptr, 0, region, cv::image_bytes(vi, kF6Slots) >> 4, ptab, sv, ck);
+        // (a team: the block's own ck.sync() has made the whole image zero before anyone writes its interior)
         // v.view(N, T, C, V) (model.py:187): flat f = c*T+t of the block output is plane channel f / C, row f % C.  Per
         // row a pedestrian's eight channels are two record quads (one per lane of the pair); the third quad (channels
         // 8..11) stays zero.
         float *d2 = wsn ? wsn + ws_plane_off(L, V, 0) : nullptr;
-        const int pw = lane & 31, q = lane >> 5;
-        if (pw < vi) {
+        const int pl = lane & 31, pw = ck.w0() + pl, q = lane >> 5;
+        if (pl < ck.wc()) {
 #pragma unroll
             for (int row = 0; row < C; ++row) {
                 const f32x4 v4 = {sv[row], sv[C + row], sv[2 * C + row], sv[3 * C + row]};
@@ -500,14 +512,14 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
                 }
             }
         }
-        if (wsn && lane < 2 * C * 3) {
+        if (wsn && lane < 2 * C * 3 && ck.lead()) {
             // zero border columns of the saved planes a_0 .. a_L (the weight-gradient GEMM reads them)
             const int b = lane / 3, q = lane - b * 3, pos = (b >> 1) * SWs + ((b & 1) ? vi + 1 : 0);
             for (int l = 0; l <= L.L; ++l)
                 store_vec4(wsn + ws_plane_off(L, V, l), pos * 3 + q, f32x4{0.f, 0.f, 0.f, 0.f}, bf16);
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    ck.sync();
 
     // ---- TXP-CNN (model.py:187-195) -------------------------------------------------------------------
     if (STG_SKIP(a, 16)) return;                       // (diagnostic build: time the block alone)
@@ -560,8 +572,8 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
             }
         }
         if (is_out) break;
-        // every tile has read a_l: a_{l+1} replaces it in the image
-        __builtin_amdgcn_wave_barrier();
+        // every tile (of every wave of a team) has read a_l: a_{l+1} replaces it in the image
+        ck.sync();
         unsigned codes[kF6Tiles];                      // (all ten table reads in flight: the weight registers are dead here)
 #pragma unroll
         for (int t = 0; t < kF6Tiles; ++t) codes[t] = cv::tile_code(t, ptab, npos);
@@ -573,7 +585,7 @@ __device__ __forceinline__ void txp_fwd_scene_x6(const TxpFwdArgs &a, const floa
                 cv::put4(img, (unsigned)(cv::pos_off(vi, 1 + (int)(hw >> 8), (int)(hw & 0xffu)) + 8 * kq), lg.PL, av[t]);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        ck.sync();
     }
 }
 
@@ -595,7 +607,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
         const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
-        txp_fwd_scene_x6<BF>(a, params, blk_p, blk_b, n, region, ptab);
+        int vi = a.num_peds ? a.num_peds[n] : a.V;
+        vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > a.V ? a.V : vi));
+        txp_fwd_scene_x6<BF>(a, params, blk_p, blk_b, n, vi, region, ptab, SoloScene{vi});
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -624,8 +638,7 @@ __device__ __forceinline__ void dgrad_layer(const float (&wreg)[27], const float
 // chain left d(a_0) position-major in `dcur` ([pos][P], channels 0..T-1); the dz plane is dead, so the block's three
 // LDS arrays are carved from the start of the wave's region: D = d(block output) [C][T][vi] | h1 [C][T+2][vi] | dh2
 // [C][T+2][vi] (140 vi floats <= plane_slot + 60 V); db1 reuses D.  Small-parameter gradients leave as the scene's own
-// row (stores, no atomics): reduce_slabs_kernel sums the rows in a fixed order.  V32: the caller guarantees vi <= 32.
-template <bool V32 = false>
+// row (stores, no atomics): reduce_slabs_kernel sums the rows in a fixed order.
 __device__ __forceinline__ void txp_bwd_block_tail(const TxpBwdArgs &a, const float *blk_params, int n, int vi,
                                                    float *dzb, float *dcur, ptab_t *ptab, float *tot, float *slope_row,
                                                    bool d_ready = false) {
@@ -642,14 +655,13 @@ __device__ __forceinline__ void txp_bwd_block_tail(const TxpBwdArgs &a, const fl
         }
     __builtin_amdgcn_wave_barrier();
     float *row = slope_row - L.n_blk_params;
-    if (V32 || (vi <= 64 && !STG_SKIP(a, 8192))) {
+    if (vi <= 64 && !STG_SKIP(a, 8192)) {
         // column mode: lane = pedestrian, all 8 time steps in registers (the mirror of the forward's column mode)
-        if (V32 || vi <= 32) stgcn_block_bwd_cols<true>(a, blk_params, L.blk[0], n, vi, D, row, a.ws + n * a.ws_stride);
+        if (vi <= 32) stgcn_block_bwd_cols<true>(a, blk_params, L.blk[0], n, vi, D, row, a.ws + n * a.ws_stride);
         else stgcn_block_bwd_cols<false>(a, blk_params, L.blk[0], n, vi, D, row, a.ws + n * a.ws_stride);
         return;
     }
-    if (!V32)
-        stgcn_block_bwd<Cfg::CIN0, 0, false>(a, blk_params, L.blk[0], n, vi, D, H1, DH2, D, nullptr, tot, row,
+    stgcn_block_bwd<Cfg::CIN0, 0, false>(a, blk_params, L.blk[0], n, vi, D, H1, DH2, D, nullptr, tot, row,
                                              a.ws + n * a.ws_stride, nullptr, nullptr, nullptr, nullptr, ptab);
 }
 
@@ -1051,23 +1063,31 @@ __host__ __device__ inline int bwd6_region_floats(int v) {
     return ((img > tail ? img : tail) + 3) & ~3;
 }
 
-template <bool BF>                 // BF: bf16 storage of z_l (read) and dz_l (written)
-__device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const float *blk_params, int n, float *region,
-                                                 ptab_t *ptab, float *tot) {
+// CK (scene_team.hpp): SoloScene -- this wave owns the scene -- or TeamScene: the wave owns the column chunk [ck.w0(),
+// ck.w0() + ck.wc()) of a scene shared by ck.nch() waves (`region` = the team's image, `ptab` = this wave's table of its
+// chunk's positions); `vi` = pedestrians of the scene.  Per-scene sums are exchanged through LDS (ck.sum), the team's
+// leading wave writes the scene's loss and its row of small-parameter gradients.
+template <bool BF, typename CK>    // BF: bf16 storage of z_l (read) and dz_l (written)
+__device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const float *blk_params, int n, int vi, float *region,
+                                                 ptab_t *ptab, const CK &ck) {
     const ModelLayout &L = a.lay;
     const int V = a.V, lane = threadIdx.x & 63, nq = lane & 15, kq = lane >> 4;
-    int vi = a.num_peds ? a.num_peds[n] : V;
-    vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
     float *slope_row = a.rows + (int64_t)n * (L.n_blk_params + L.n_txp) + L.n_blk_params;
     if (vi == 0) {                                     // empty scene: its row of small-parameter gradients is zero
         for (int e = lane; e < L.n_blk_params + L.n_txp; e += 64) slope_row[e - L.n_blk_params] = 0.f;
         if (a.nll_target && lane == 0) a.nll_losses[n] = 0.f;
         return;
     }
-    const int npos = C * vi, ntiles = (npos + 15) >> 4;
+    const int npos = C * ck.wc(), ntiles = (npos + 15) >> 4;      // this wave's positions: (row, its columns)
     const float *Pm = a.params;
     const float *wsn = a.ws + n * a.ws_stride;
     const float *dyn = a.dy + (int64_t)n * (C * P) * V;
+    // sums that only leave the kernel (PReLU slope gradients, the loss, the block's parameter gradients): a solo wave writes
+    // them to the scene's row; the waves of a team park theirs in LDS rows (zeroed here) that the leading wave adds at the end
+    float *prow = ck.row(slope_row - L.n_blk_params);
+    if constexpr (CK::kTeam) {
+        for (int e = lane; e < kTeamRow; e += 64) prow[e] = 0.f;
+    }
     unsigned char *img = reinterpret_cast<unsigned char *>(region);
     const cv::LaneGeom lg = cv::lane_geom(vi, kX6Slots);
     constexpr bool bf16 = BF;
@@ -1084,10 +1104,10 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
     };
     {
         uint4 *z4 = reinterpret_cast<uint4 *>(img);
-        for (int e = lane; e < cv::image_bytes(vi, kX6Slots) >> 4; e += 64) z4[e] = make_uint4(0u, 0u, 0u, 0u);
+        for (int e = lane + 64 * ck.ci(); e < cv::image_bytes(vi, kX6Slots) >> 4; e += 64 * ck.nch()) z4[e] = make_uint4(0u, 0u, 0u, 0u);
     }
-    build_ptab(ptab, vi);
-    __builtin_amdgcn_wave_barrier();
+    build_ptab(ptab, ck.w0(), ck.wc());
+    ck.sync();
     f32x4 dcur[kX6Tiles];
 #pragma unroll
     for (int t = 0; t < kX6Tiles; ++t) dcur[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1100,10 +1120,11 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
             // dz of the output conv is dV_pred: row rc = f * P + p of the (C*P) x V array is channel rc / C, plane row
             // rc % C.  Lanes are laid over (row or prediction step, pedestrian) with the row length rounded up to a power
             // of two.
-            const int vp = vi <= 1 ? 1 : (vi <= 2 ? 2 : (vi <= 4 ? 4 : (vi <= 8 ? 8 : (vi <= 16 ? 16 : 32))));
+            const int wcw = ck.wc();
+            const int vp = wcw <= 1 ? 1 : (wcw <= 2 ? 2 : (wcw <= 4 ? 4 : (wcw <= 8 ? 8 : (wcw <= 16 ? 16 : 32))));
             const int sh = __builtin_ctz(vp), rpi = 64 >> sh;
-            const int sub = lane >> sh, w = lane & (vp - 1);
-            const bool okw = w < vi;
+            const int sub = lane >> sh, wl = lane & (vp - 1), w = ck.w0() + wl;      // the lane's pedestrian
+            const bool okw = wl < wcw;
             // the values pass through an fp32 staging array S [C*P rows][vi] laid over the (still empty) m / l piece
             // images: coalesced along the pedestrians here, read back as record quads below
             float *S = reinterpret_cast<float *>(img + lg.PL);
@@ -1125,8 +1146,12 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
                         for (int f = 0; f < C; ++f) put1(f * P + p, g[f] * gs);
                     }
                 }
-                lacc = wave_sum(lacc);
-                if (lane == 0) a.nll_losses[n] = lacc * inv_cnt;
+                float ls[1] = {lacc};
+                ck.template reduce<1>(ls);
+                if (ck.writer()) {
+                    if constexpr (CK::kTeam) prow[kTeamRowLoss] = ls[0];
+                    else a.nll_losses[n] = ls[0] * inv_cnt;
+                }
             } else {
                 constexpr int U = 4;
                 for (int r0 = 0; r0 < C * P; r0 += rpi * U) {
@@ -1158,12 +1183,12 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
                 const float *sq = S + ((4 * (kq < 3 ? kq : 0)) * C + (int)(hw >> 8)) * vi + (int)(hw & 0xffu);
                 qd[t] = f32x4{sq[0], sq[C * vi], sq[2 * C * vi], sq[3 * C * vi]};
             }
-            __builtin_amdgcn_wave_barrier();
+            ck.sync();                                  // (every wave of a team has its quads: S may be wiped)
             {
                 uint4 *z4 = reinterpret_cast<uint4 *>(img + lg.PL);
-                for (int e = lane; e < (2 * lg.PL + 128) >> 4; e += 64) z4[e] = make_uint4(0u, 0u, 0u, 0u);
+                for (int e = lane + 64 * ck.ci(); e < (2 * lg.PL + 128) >> 4; e += 64 * ck.nch()) z4[e] = make_uint4(0u, 0u, 0u, 0u);
             }
-            __builtin_amdgcn_wave_barrier();
+            ck.sync();
             int rec[kX6Tiles], qv[kX6Tiles];           // (the table reads of all ten tiles in flight together)
 #pragma unroll
             for (int t = 0; t < kX6Tiles; ++t) tile_slots(t, rec[t], qv[t]);
@@ -1215,10 +1240,11 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
                     store_vec4(dzo, qv[t], dzv, bf16);
                 }
             }
-            slope_acc = wave_sum(slope_acc);
-            if (lane == 0) slope_row[l] = slope_acc;
+            float ss[1] = {slope_acc};
+            ck.template reduce<1>(ss);
+            if (ck.writer()) prow[L.n_blk_params + l] = ss[0];
         }
-        __builtin_amdgcn_wave_barrier();
+        ck.sync();
         // ---- d(a_l) = conv_transpose(dz_l, W_l) [+ d(a_{l+1}) through the residual of the hidden layers] ----------------
         if (!STG_SKIP(a, 1024)) {
             cv::u32x4 w[cv::kWpVecs];
@@ -1246,7 +1272,7 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        ck.sync();
     }
     // ---- d(a_0) (channels 0..T-1) -> D [C][T][vi] at the start of the region: v.view(N, T, C, V) (model.py:187)
     // backwards, plane (ch, row) is flat f = ch*C + row = c*T + t of the block output.  The dz image is dead.
@@ -1261,8 +1287,28 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
             for (int r = 0; r < 4; ++r) D[((4 * kq + r) * C + h) * vi + ww] = dcur[t][r];
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    txp_bwd_block_tail<true>(a, blk_params, n, vi, region, nullptr, ptab, tot, slope_row, true);
+    __builtin_amdgcn_wave_barrier();                  // (a lane reads back its own wave's columns of D)
+    // ---- the st_gcn block (model.py:145-155 backwards), column mode: lane = (pedestrian, time half) ------------------------
+    if constexpr (!CK::kTeam) {
+        for (int e = L.L + lane; e < L.n_txp; e += 64) slope_row[e] = 0.f;       // dead slopes (layers >= L)
+    }
+    if (!STG_SKIP(a, 4))
+        stgcn_block_bwd_cols<true>(a, blk_params, L.blk[0], n, vi, D, slope_row - L.n_blk_params, a.ws + n * a.ws_stride, ck);
+    if constexpr (CK::kTeam) {
+        // the team's parked rows -> the scene's row of small-parameter gradients and its loss, added in chunk order
+        ck.sync();
+        if (ck.lead()) {
+            float *row = slope_row - L.n_blk_params;
+            const int nrow = L.n_blk_params + L.n_txp;
+            for (int e0 = 0; e0 < kTeamRow; e0 += 64) {
+                const int e = e0 + lane < kTeamRow ? e0 + lane : kTeamRow - 2;      // (a spare place, never stored)
+                float t = ck.row_of(0)[e];
+                for (int c = 1; c < ck.nch(); ++c) t += ck.row_of(c)[e];
+                if (e < nrow) row[e] = t;
+                if (e == kTeamRowLoss && a.nll_target) a.nll_losses[n] = t * (1.0f / (float)(P * vi));
+            }
+        }
+    }
 }
 
 template <int WPB, bool BF>
@@ -1273,7 +1319,6 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
     const int per_wave = bwd6_region_floats(Vl) + bwd_ptab_floats(Vl);
     float *region = sm + wave * per_wave;
     ptab_t *ptab = reinterpret_cast<ptab_t *>(region + bwd6_region_floats(Vl));
-    float *tot = region + bwd6_region_floats(Vl) + ptab_floats(Vl);
     float *blk_p = sm + WPB * per_wave;
     stage_block_params(a.lay, a.params, nullptr, blk_p, nullptr, WPB * 64);
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave), nw = gridDim.x * WPB;
@@ -1284,7 +1329,136 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
         const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
         if (it < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
-        txp_bwd_scene_x6<BF>(a, blk_p, n, region, ptab, tot);
+        int vi = a.num_peds ? a.num_peds[n] : a.V;
+        vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > a.V ? a.V : vi));
+        txp_bwd_scene_x6<BF>(a, blk_p, n, vi, region, ptab, SoloScene{vi});
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// team launch: scenes of 1 .. kTeamMaxV pedestrians in ONE launch, one / two / four waves per scene (scene_team.hpp)
+// ------------------------------------------------------------------------------------------
+// Work units of a launch, in list order: one per four-wave scene, one per PAIR of two-wave scenes, one per four solo scenes
+// (the sorted list is descending, so the units come heaviest first).  A workgroup takes the units of a fixed walk; all four
+// waves of a workgroup are always in the same kind of unit, so the workgroup barriers inside the scene code match.
+struct TeamCount {
+    int n4, n2, n1;        // scenes per class (sorted list: [0, n4) | [n4, n4 + n2) | the rest)
+    int u4, u2, units;
+    bool sorted;
+};
+__device__ __forceinline__ TeamCount team_count(const SceneTier &t, const TeamGeom &g, const int32_t *num_peds, int N, int V) {
+    TeamCount c;
+    c.sorted = t.order && t.key_start;
+    if (c.sorted) {
+        // key_start[k] = number of scenes with more than V - k pedestrians
+        const int a4 = g.v2 < V ? t.key_start[V - g.v2] : 0, a2 = g.v1 < V ? t.key_start[V - g.v1] : 0;
+        c.n4 = a4;
+        c.n2 = a2 - a4;
+        c.u2 = (c.n2 + 1) >> 1;
+    } else {
+        // no sorted list: every scene in the class of the padded V.  With num_peds (a single scene, a batch beyond the sort's
+        // limits) no pairs of two-wave scenes -- an EMPTY scene may only leave the barrier sequence together with its whole
+        // workgroup
+        const bool pairs = !num_peds && V > g.v1 && V <= g.v2;
+        c.n4 = (V > g.v1 && !pairs) ? N : 0;
+        c.n2 = pairs ? N : 0;
+        c.u2 = (c.n2 + 1) >> 1;
+    }
+    c.n1 = N - c.n4 - c.n2;
+    c.u4 = c.n4;
+    c.units = c.u4 + c.u2 + ((c.n1 + 3) >> 2);
+    return c;
+}
+struct TeamUnit {
+    int n, vi;             // scene (n < 0: this wave idles this round) and its pedestrians
+    int nch, ci, slot;     // waves on the scene, this wave's place among them, which of the round's 4 / nch scenes
+    int w0, wc;            // this wave's column chunk
+};
+__device__ __forceinline__ TeamUnit team_unit(const SceneTier &t, const TeamCount &c, const int32_t *__restrict__ num_peds,
+                                              int N, int V, int u) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TeamUnit q;
+    int idx;
+    if (u < c.u4) {
+        q.nch = 4; q.slot = 0; q.ci = wave; idx = u;
+    } else if (u < c.u4 + c.u2) {
+        const int i0 = c.n4 + 2 * (u - c.u4);
+        if (i0 + 1 < c.n4 + c.n2) { q.nch = 2; q.slot = wave >> 1; q.ci = wave & 1; idx = i0 + q.slot; }
+        else { q.nch = 4; q.slot = 0; q.ci = wave; idx = i0; }           // the odd one out takes the whole workgroup
+    } else {
+        q.nch = 1; q.slot = wave; q.ci = 0; idx = c.n4 + c.n2 + 4 * (u - c.u4 - c.u2) + wave;
+    }
+    q.n = idx < N ? (c.sorted ? t.order[idx] : idx) : -1;
+    q.n = __builtin_amdgcn_readfirstlane(q.n);
+    int vi = q.n >= 0 ? (num_peds ? num_peds[q.n] : V) : 0;
+    vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
+    q.vi = vi;
+    const int wc = (vi + q.nch - 1) / q.nch;          // equal chunks; the last one may be short (or empty)
+    q.w0 = q.ci * wc;
+    q.wc = vi - q.w0 < wc ? (vi - q.w0 > 0 ? vi - q.w0 : 0) : wc;
+    return q;
+}
+// equal shares: the fewest rounds the grid can do, then just enough workgroups for them
+__device__ __forceinline__ int team_workers(int units, int grid) {
+    const int rounds = (units + grid - 1) / grid;
+    return rounds > 0 ? (units + rounds - 1) / rounds : 1;
+}
+__host__ __device__ inline int team_ptab_floats() { return ptab_floats(32); }
+
+template <bool BF>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_fwd_team_kernel(
+    const TxpFwdArgs a, const float *__restrict__ params, const float *__restrict__ buffers) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int R = a.team.region_floats;
+    ptab_t *ptab = reinterpret_cast<ptab_t *>(sm + R + wave * team_ptab_floats());
+    float *xr = sm + R + 4 * team_ptab_floats();
+    float *blk_p = xr + 2 * kXrFwd, *blk_b = blk_p + ((a.lay.n_blk_params + 3) & ~3);
+    stage_block_params(a.lay, params, buffers, blk_p, blk_b, 256);
+    const TeamCount tc = team_count(a.tier, a.team, a.num_peds, a.N, a.V);
+    const int G = team_workers(tc.units, gridDim.x);
+    int prev = 1;
+    for (int r = 0; r * G < tc.units; ++r) {
+        const int u = walk_item(r, blockIdx.x, G, tc.units, a.tier.serpentine != 0);
+        if (u < 0 || (int)blockIdx.x >= G) continue;
+        const TeamUnit q = team_unit(a.tier, tc, a.num_peds, a.N, a.V, u);
+        if (q.nch > 1 || prev > 1) team_barrier();     // (the previous round is over before a region changes hands)
+        prev = q.nch;
+        if (q.n >= 0) {
+            const TeamScene ck{q.vi, q.w0, q.wc, q.nch, q.ci, xr + (q.slot & 1) * kXrFwd, nullptr, q.nch > 1 && !STG_SKIP(a, 1 << 20)};
+            float *region = sm + q.slot * ((R >> 2) * q.nch);
+            txp_fwd_scene_x6<BF>(a, params, blk_p, blk_b, q.n, q.vi, region, ptab, ck);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void txp_bwd_team_kernel(const TxpBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int R = a.team.region_floats;
+    ptab_t *ptab = reinterpret_cast<ptab_t *>(sm + R + wave * team_ptab_floats());
+    float *xr = sm + R + 4 * team_ptab_floats();
+    float *blk_p = xr + kXrBwdWg;
+    stage_block_params(a.lay, a.params, nullptr, blk_p, nullptr, 256);
+    const TeamCount tc = team_count(a.tier, a.team, a.num_peds, a.N, a.V);
+    const int G = team_workers(tc.units, gridDim.x);
+    int prev = 1;
+    for (int r = 0; r * G < tc.units; ++r) {
+        const int u = walk_item(r, blockIdx.x, G, tc.units, a.tier.serpentine != 0);
+        if (u < 0 || (int)blockIdx.x >= G) continue;
+        const TeamUnit q = team_unit(a.tier, tc, a.num_peds, a.N, a.V, u);
+        if (q.nch > 1 || prev > 1) team_barrier();
+        prev = q.nch;
+        if (q.n >= 0) {
+            // (a team of nch waves is waves slot * nch .. slot * nch + nch - 1 of the workgroup: their parked rows are adjacent)
+            const TeamScene ck{q.vi, q.w0, q.wc, q.nch, q.ci, xr + (q.slot & 1) * kXrRows,
+                               xr + 2 * kXrRows + q.slot * q.nch * kTeamRow, q.nch > 1 && !STG_SKIP(a, 1 << 20)};
+            float *region = sm + q.slot * ((R >> 2) * q.nch);
+            txp_bwd_scene_x6<BF>(a, blk_p, q.n, q.vi, region, ptab, ck);
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1422,8 +1596,9 @@ static int wave_grid(size_t lds, int wpb, int N) {
 bool txp_wave_fits(const ModelLayout &L, int V) {
     if (L.n_txp < 1 || L.n_blocks != 1 || L.blk[0].cin != Cfg::CIN0) return false;
     if (L.flags & STG_OPT_WG_PATH) return false;
+    if (txp_fwd_x6_fits(L, V) && txp_bwd_x6_fits(L, V)) return true;      // the exact-bf16 kernels (teams of waves beyond 32)
     const size_t fwd = (size_t)2 * plane_slot(V) * sizeof(float);
-    return fwd <= 48 * 1024;        // at least three waves per CU
+    return fwd <= 48 * 1024;        // the fp32-MFMA wave kernels: at least three waves per CU
 }
 
 constexpr int kSmallBatch = 288;      // measured: 256 scenes 1.89 (workgroup kernels) vs 1.79 M/s (a wave per scene), 320 scenes 2.10 vs 2.19
@@ -1465,13 +1640,58 @@ static int mix_grid(size_t lds_bytes, int N) {
 }
 
 bool txp_fwd_x6_fits(const ModelLayout &L, int V) {
-    return L.n_txp > 0 && V <= 16 * kF6Tiles / C && !(L.flags & STG_OPT_F32_MFMA) && L.n_blocks == 1 &&
+    return L.n_txp > 0 && V <= kTeamMaxV && !(L.flags & STG_OPT_F32_MFMA) && L.n_blocks == 1 &&
            L.blk[0].cin == Cfg::CIN0 && !diag_env("STG_FWD_F32", 0);
+}
+
+// Team launch geometry.  Class bounds: a scene of up to v1 pedestrians belongs to one wave, up to v2 to two, beyond to four
+// (a wave's chunk is at most 32 columns = 10 tiles).  Large batches fill the chip with whole scenes (32 / 64); a small
+// batch is latency-bound -- every scene's dependency chain IS the step -- so its scenes are cut finer.
+static bool team_geom(int N, int V, bool fwd, TeamGeom *g) {
+    g->on = 0;
+    if (V > kTeamMaxV) return false;
+    int v1 = 32, v2 = 64;
+    if (const int e = diag_env("STG_TEAM_V1", 0)) v1 = e;
+    if (const int e = diag_env("STG_TEAM_V2", 0)) v2 = e;
+    (void)N;
+    if (v1 > 32) v1 = 32;
+    if (v2 > 64) v2 = 64;
+    if (v2 < v1) v2 = v1;
+    // (the backward's column-mode block needs D = [C][T][v] of the dead image, not the LDS arrays of bwd6_region_floats)
+    auto region = [&](int v) { return fwd6_region_floats(v); };
+    (void)fwd;
+    int r = 4 * region(v1 < V ? v1 : V);
+    if (2 * region(v2 < V ? v2 : V) > r) r = 2 * region(v2 < V ? v2 : V);
+    if (region(V) > r) r = region(V);
+    g->on = 1; g->v1 = v1; g->v2 = v2; g->region_floats = (r + 15) & ~15;
+    return true;
+}
+static int team_grid(size_t lds_bytes, int N) {
+    int per_cu = (int)(kLdsBytes / lds_bytes);
+    if (per_cu > 2) per_cu = 2;                        // 256-register kernels: two waves per SIMD
+    if (per_cu < 1) per_cu = 1;
+    const int g = kNumCU * per_cu;
+    return g < N ? g : N;                              // (at most one unit per scene)
 }
 
 int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
     TxpFwdArgs a = a0;
-    if (a.wpf && txp_fwd_x6_fits(a.lay, a.V)) {
+    if (a.wpf && txp_fwd_x6_fits(a.lay, a.V) && (a.V > 16 * kF6Tiles / C || diag_env("STG_TEAM", 0)) &&
+        team_geom(a.N, a.V, true, &a.team)) {
+        const size_t lds = ((size_t)a.team.region_floats + 4 * team_ptab_floats() + 2 * kXrFwd + wave_param_floats(a.lay)) * sizeof(float);
+        STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "txp_fwd_team: V=%d needs %zu bytes of LDS", a.V, lds);
+        const bool bf = (a.lay.flags & STG_OPT_BF16_STORE) != 0;
+        const void *fn = bf ? reinterpret_cast<const void *>(&txp_fwd_team_kernel<true>)
+                            : reinterpret_cast<const void *>(&txp_fwd_team_kernel<false>);
+        hipError_t e_ = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e_ != hipSuccess) return hip_fail(e_, "txp_fwd_team: hipFuncSetAttribute");
+        const dim3 grid(team_grid(lds, a.N));
+        if (bf) hipLaunchKernelGGL(txp_fwd_team_kernel<true>, grid, dim3(256), lds, st, a, a.params, a.buffers);
+        else hipLaunchKernelGGL(txp_fwd_team_kernel<false>, grid, dim3(256), lds, st, a, a.params, a.buffers);
+        STG_LAUNCH_CHECK("txp_fwd_team");
+        return STG_OK;
+    }
+    if (a.wpf && txp_fwd_x6_fits(a.lay, a.V) && a.V <= 16 * kF6Tiles / C) {
         const size_t per_wave = (size_t)(fwd6_region_floats(a.Vl) + ptab_floats(a.Vl)) * sizeof(float);
         const int wpb = wave_wpb(per_wave) == 8 ? 8 : 4;     // (the 18 KB images of V <= 32 always fit four waves)
         const size_t lds = per_wave * wpb + wave_param_floats(a.lay) * sizeof(float);
@@ -1517,13 +1737,28 @@ int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
 }
 
 bool txp_bwd_x6_fits(const ModelLayout &L, int V) {
-    return L.n_txp > 0 && V <= 16 * kX6Tiles / C &&
+    return L.n_txp > 0 && V <= kTeamMaxV && L.n_blocks == 1 && L.blk[0].cin == Cfg::CIN0 &&
            !(L.flags & (STG_OPT_SPLIT_BF16 | STG_OPT_F32_MFMA)) && !diag_env("STG_BWD_F32", 0);
 }
 int64_t txp_bwd_x6_wp_floats(const ModelLayout &L) { return (int64_t)(L.L + 1) * cv::kWpDwords; }
 int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {
     TxpBwdArgs a = a0;
-    if (a.wp && txp_bwd_x6_fits(a.lay, a.V)) {
+    if (a.wp && txp_bwd_x6_fits(a.lay, a.V) && (a.V > 16 * kX6Tiles / C || diag_env("STG_TEAM", 0)) &&
+        team_geom(a.N, a.V, false, &a.team)) {
+        const size_t lds = ((size_t)a.team.region_floats + 4 * team_ptab_floats() + kXrBwdWg + wave_param_floats(a.lay)) * sizeof(float);
+        STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "txp_bwd_team: V=%d needs %zu bytes of LDS", a.V, lds);
+        const bool bf = (a.lay.flags & STG_OPT_BF16_STORE) != 0;
+        const void *fn = bf ? reinterpret_cast<const void *>(&txp_bwd_team_kernel<true>)
+                            : reinterpret_cast<const void *>(&txp_bwd_team_kernel<false>);
+        hipError_t e_ = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e_ != hipSuccess) return hip_fail(e_, "txp_bwd_team: hipFuncSetAttribute");
+        const dim3 grid(team_grid(lds, a.N));
+        if (bf) hipLaunchKernelGGL(txp_bwd_team_kernel<true>, grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(txp_bwd_team_kernel<false>, grid, dim3(256), lds, st, a);
+        STG_LAUNCH_CHECK("txp_bwd_team");
+        return STG_OK;
+    }
+    if (a.wp && txp_bwd_x6_fits(a.lay, a.V) && a.V <= 16 * kX6Tiles / C) {
         const size_t per_wave = (size_t)(bwd6_region_floats(a.Vl) + bwd_ptab_floats(a.Vl)) * sizeof(float);
         const int wpb = wave_wpb(per_wave) == 8 ? 8 : 4;
         const size_t lds = per_wave * wpb + wave_param_floats(a.lay) * sizeof(float);

@@ -15,6 +15,17 @@ struct MixGeom {
     int block_floats;     // LDS floats of one workgroup = 4 * per-wave floats at v_small
 };
 
+// Team launch of the exact-bf16 kernels (batches padded beyond 32 pedestrians; small batches): ONE launch of 4-wave
+// workgroups in which a scene-window is worked on by one, two or four waves (scene_team.hpp) according to its crowd:
+// V_n <= v1 one wave (four scenes per workgroup round), V_n <= v2 two waves (two scenes per round), larger ones four.
+// The workgroups read the class sizes from the tier offsets of the sorted scene list on the device (no host sync).
+constexpr int kTeamMaxV = 128;       // four chunks of 32 columns
+struct TeamGeom {
+    int on;
+    int v1, v2;           // class bounds (v1 <= 32, v2 <= 64)
+    int region_floats;    // LDS floats of a workgroup's image region: one four-wave scene, two two-wave scenes, four solo scenes
+};
+
 // forward: the WHOLE model per scene -- st_gcn block (from the aggregated input stgcn_agg_kernel left) + TXP-CNN
 struct TxpFwdArgs {
     ModelLayout lay;
@@ -23,6 +34,7 @@ struct TxpFwdArgs {
     SceneTier tier;        // which scenes this launch serves (ragged batches: sorted, walked boustrophedon)
     int Vl;                // LDS geometry of the launch: >= every V_n of the tier (<= V)
     MixGeom mix;
+    TeamGeom team;
     int N, V;
     const float *x;        // (N, c_in, T, V) strided block input (residual branch)
     int64_t x_sn, x_sc, x_st, x_sv;
@@ -48,6 +60,7 @@ struct TxpBwdArgs {
     SceneTier tier;        // which scenes this launch serves (ragged batches: sorted, walked boustrophedon)
     int Vl;                // LDS geometry of the launch: >= every V_n of the tier (<= V)
     MixGeom mix;
+    TeamGeom team;
     int N, V;
     const float *x;        // (N, c_in, T, V) strided block input (residual branch)
     int64_t x_sn, x_sc, x_st, x_sv;
@@ -80,7 +93,7 @@ bool use_wave_path(const ModelLayout &L, int N, int V, int *wg_waves);
 int64_t ws_tail_wp_floats(const ModelLayout &l, int V);      // model_fwd.hip: floats of the operand part of the workspace's batch tail
 int launch_txp_fwd_wave(const TxpFwdArgs &a, hipStream_t st);
 int launch_txp_bwd_wave(const TxpBwdArgs &a, hipStream_t st);
-// the exact-bf16 input-gradient chain (txp_bwd_x6): serves whole batches with V <= 32, fp32 storage
+// the exact-bf16 kernels (txp_fwd_x6 / txp_bwd_x6 and their team forms): V <= kTeamMaxV
 bool txp_bwd_x6_fits(const ModelLayout &L, int V);
 bool txp_fwd_x6_fits(const ModelLayout &L, int V);
 int64_t txp_bwd_x6_wp_floats(const ModelLayout &L);

@@ -37,11 +37,14 @@ def test_layout_queries_match_reference_counts(L):
     assert L.stg_model_stat_floats(ctypes.byref(d)) == 30
     assert L.stg_model_ws_floats(ctypes.byref(d), 32) == 64 + 32 * (16 + 8 + 40 + 40 + 40 + 4 * 60) + 5 * 12 * 240
     # batch tail of the workspace: the prepared bf16 A operands of the five input-gradient convs (24 x 64 lanes x 16 bytes
-    # each) when the exact-bf16 backward serves the batch (V <= 32), nothing otherwise; behind them the scene order of a
-    # ragged batch (N indices, V + 2 tier offsets, N sorted counts, rounded up to 4)
+    # each) when the exact-bf16 backward serves the batch (V <= 128: one wave per scene up to 32 pedestrians, teams of two
+    # or four waves beyond), nothing otherwise; behind them the scene order of a ragged batch (N indices, V + 2 tier
+    # offsets, N sorted counts, rounded up to 4)
     order = lambda n, v: (2 * n + v + 2 + 3) & ~3
     assert L.stg_model_ws_tail_floats(ctypes.byref(d), 100, 32) == 5 * 24 * 64 * 4 + order(100, 32)
-    assert L.stg_model_ws_tail_floats(ctypes.byref(d), 7, 64) == order(7, 64)
+    assert L.stg_model_ws_tail_floats(ctypes.byref(d), 7, 64) == 5 * 24 * 64 * 4 + order(7, 64)
+    assert L.stg_model_ws_tail_floats(ctypes.byref(d), 7, 128) == 5 * 24 * 64 * 4 + order(7, 128)
+    assert L.stg_model_ws_tail_floats(ctypes.byref(d), 7, 129) == order(7, 129)
     d_f32 = ops.make_desc(1, 5, 2, 5, 8, 12, 3, 2, False, True)
     from social_stgcnn_amd import _lib as lib_mod
     d_f32.flags |= lib_mod.OPT_F32_MFMA

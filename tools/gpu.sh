@@ -55,5 +55,12 @@ sweep)
     timeout -k 10 600 python bench.py --no-cpu-baseline --no-extras --repeats 8 --steps 20 $args 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('$args:', '%.3f M/s  %.3f ms/step' % (d['value']/1e6, d['ms_per_step']))" ; done | tee gpurun_out/$tag.sweep.log ;;
-*) echo "usage: tools/gpu.sh test|bench|prof|pmc|sweep ..."; exit 2 ;;
+ksweep)
+  # per-kernel device times (us) of a list of configurations: tools/gpu.sh ksweep "--peds 64" "--dataset eth-train --batch 512" ...
+  for args in "$@"; do
+    timeout -k 10 600 python bench.py --no-cpu-baseline --kernels-only --repeats 8 --steps 20 $args 2>gpurun_out/$tag.err | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); ks=d['roofline']['kernels']
+print('%-36s %.3f M/s  %.3f ms/step |' % ('$args', d['value']/1e6, d['ms_per_step']), '  '.join('%s %.1f' % (k['kernel'].split(' ')[0].replace('_kernel','').replace('txp_','').replace('stgcn_',''), k['launch_ms']*1e3) for k in ks))" ; done | tee gpurun_out/$tag.ksweep.log ;;
+*) echo "usage: tools/gpu.sh test|bench|prof|pmc|sweep|ksweep ..."; exit 2 ;;
 esac
