@@ -152,7 +152,8 @@ def eth_train_batches(n, n_batches, seed):
     out = []
     for b in range(n_batches):
         idx = np.sort(perm[(b * n) % len(win):][:n]) if (b * n) % len(win) + n <= len(win) else np.sort(perm[:n])
-        obs_rel, pred_rel, _, _, counts = data.pad_batch(win, idx)
+        v_pad = (int(win.num_peds[idx].max()) + 3) & ~3          # (16-byte aligned adjacency rows)
+        obs_rel, pred_rel, _, _, counts = data.pad_batch(win, idx, v_pad=v_pad)
         out.append((np.ascontiguousarray(np.transpose(obs_rel, (0, 2, 3, 1))), pred_rel, counts))
     return out, len(win)
 
@@ -347,6 +348,7 @@ def main():
     model = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=T_OBS, kernel_size=3,
                           pred_seq_len=T_PRED).to(dev).train()
     broadcast_module(model)
+    init_state = {k: t.detach().clone() for k, t in model.state_dict().items()}
     trainer = Trainer(model, lr=0.01)
 
     def eager(d):
@@ -501,14 +503,19 @@ def main():
         win = data.load_windows(os.path.join(ROOT, "tests", "golden", "data", "eth_train"), T_OBS, T_PRED, 1,
                                 with_non_linear=False)
         ds = DeviceWindows(win, dev)
+        # from the seeded initial weights again: thousands of timed steps on two fixed batches leave an over-fitted model
+        # whose correlation output can saturate on unseen windows (rho = +-1 -> a NaN loss, like the reference's)
+        model.load_state_dict(init_state)
         runner = EpochRunner(trainer, ds, n)
         gen = torch.Generator(device=dev).manual_seed(0)
         runner.train_epoch(ds.shuffled_order(gen))                       # capture + warm-up epoch
         torch.cuda.synchronize()
         n_ep = 20
+        ep_losses = []
         t0 = time.perf_counter()
         for _ in range(n_ep):
             last = runner.train_epoch(ds.shuffled_order(gen))
+            ep_losses.append(last)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out["epoch"] = {"what": "reference-style training epochs (train.py:28-79 group semantics, batch_size %d) over the "
@@ -516,7 +523,8 @@ def main():
                                 "adjacency build, step -- ONE captured hipGraph per group, no host->device traffic in "
                                 "the loop" % (n, len(ds)),
                         "epochs": n_ep, "seconds_per_epoch": dt / n_ep, "value": n_ep * len(ds) / dt,
-                        "unit": "scene-windows/s", "last_epoch_loss": float(last)}
+                        "unit": "scene-windows/s", "first_epoch_loss": float(ep_losses[0]),
+                        "last_epoch_loss": float(last)}
 
     # ---- stand-alone HBM kernels on a working set beyond the Infinity Cache (rank 0) --------------------------------
     if rank == 0 and not args.no_extras and not args.kernels_only:

@@ -80,10 +80,17 @@ __global__ __launch_bounds__(256) void adj_build_kernel(
     }
     float *out = adj + (int64_t)n * T * V * V;
     if (VEC4) {
+        // lanes = (row within a group of rows, 16-byte column chunk), the chunk count rounded up to a power of two: no
+        // integer division per element (rows of 57 -> 60 pedestrians: 15 chunks on 16 lanes), (t, h) advance incrementally
         const int v4 = V >> 2;
-        for (int e = tid; e < T * V * v4; e += blockDim.x) {
-            const int th = e / v4, k0 = (e - th * v4) << 2;
-            const int t = th / V, h = th - t * V;
+        int cw = 1;
+        while (cw < v4) cw <<= 1;
+        if (cw > (int)blockDim.x) cw = blockDim.x;
+        const int rows_per_pass = blockDim.x / cw, r0 = tid / cw, c0 = tid - r0 * cw;
+        int t = r0 / V, h = r0 - t * V;
+        for (int th = r0; th < T * V; th += rows_per_pass) {
+          for (int c = c0; c < v4; c += cw) {
+            const int k0 = c << 2, e = th * v4 + c;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (h < vi) {
                 const float *qx = px + t * V, *qy = py + t * V, *qd = dinv + t * V;
@@ -113,6 +120,9 @@ __global__ __launch_bounds__(256) void adj_build_kernel(
                 o = make_float4(vals[0], vals[1], vals[2], vals[3]);
             }
             reinterpret_cast<float4 *>(out)[e] = o;
+          }
+          h += rows_per_pass;
+          while (h >= V) { h -= V; ++t; }
         }
     } else {
         for (int e = tid; e < T * V * V; e += blockDim.x) {

@@ -627,6 +627,7 @@ static int model_bwd_impl(const stg_model_desc *d, const float *params, const fl
         r.seg[r.n_seg++] = ReduceSeg{L.prelus, L.n_txp, slab_rows, n_small, cv.rows + (int64_t)L.n_blk_params};
         WgradArgs w{};
         w.lay = L; w.num_peds = num_peds; w.order = a.tier.order; w.order_peds = sorted ? order_peds : nullptr;
+        w.key_start = a.tier.key_start;
         w.serpentine = a.tier.serpentine; w.N = N; w.V = V;
         w.ws = ws; w.dzg = dzg; w.ws_stride = a.ws_stride; w.slab2 = slab2; w.rows = wg.rows; w.debug_skip = a.debug_skip;
         for (int l = 0; l <= L.L + 1; ++l) w.wg_begin[l] = wg.wg_begin[l];

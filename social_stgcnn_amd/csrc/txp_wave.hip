@@ -1606,6 +1606,7 @@ constexpr int kSmallBatch = 288;      // measured: 256 scenes 1.89 (workgroup ke
 bool use_wave_path(const ModelLayout &L, int N, int V, int *wg_waves) {
     if (wg_waves) *wg_waves = L.wg_waves;
     if (!txp_wave_fits(L, V)) return false;
+    if (txp_fwd_x6_fits(L, V) && txp_bwd_x6_fits(L, V)) return true;     // (small batches: finer teams, see team_geom)
     if (N >= kSmallBatch || L.wg_waves != 0 || V > 40 || (L.flags & (STG_OPT_WAVE_PATH | STG_OPT_BF16_STORE))) return true;
     // small batch of small scenes: 2048 resident wave slots / N scenes, at most the 8 waves a scene's tiles can use
     if (wg_waves) *wg_waves = N <= 192 ? 8 : 4;
@@ -1647,24 +1648,38 @@ bool txp_fwd_x6_fits(const ModelLayout &L, int V) {
 // Team launch geometry.  Class bounds: a scene of up to v1 pedestrians belongs to one wave, up to v2 to two, beyond to four
 // (a wave's chunk is at most 32 columns = 10 tiles).  Large batches fill the chip with whole scenes (32 / 64); a small
 // batch is latency-bound -- every scene's dependency chain IS the step -- so its scenes are cut finer.
-static bool team_geom(int N, int V, bool fwd, TeamGeom *g) {
+// A small batch is latency-bound -- with fewer scene-waves than the chip has SIMDs every scene's dependency chain IS the
+// step -- so its scenes are cut finer (measured, synthetic V = 32 / eth-train histogram, M scene-windows/s: N = 256
+// 1.88 -> 2.17 at (8, 16); N = 512 3.27 -> 3.71, eth/train x 512 3.07 -> 3.57 at (16, 32); N = 1024 5.52 -> 5.74 / 5.57 ->
+// 6.33 at (16, 32); profiles/r03_team_bounds.log).  `uniform` (no num_peds): every scene has V pedestrians, the number of
+// scene-waves is known -- never cut so fine that they no longer fit the chip's 2048 wave slots at once.
+constexpr int kTeamFineBatch = 1536, kTeamFinestBatch = 384;
+static int team_waves(int v, int v1, int v2) { return v <= v1 ? 1 : (v <= v2 ? 2 : 4); }
+static bool team_geom(int N, int V, bool uniform, TeamGeom *g) {
     g->on = 0;
     if (V > kTeamMaxV) return false;
     int v1 = 32, v2 = 64;
+    if (N < kTeamFinestBatch) { v1 = 8; v2 = 16; }
+    else if (N < kTeamFineBatch) { v1 = 16; v2 = 32; }
+    if (uniform)
+        while (v1 < 32 && (int64_t)N * team_waves(V, v1, v2) > 2048) { v1 *= 2; v2 *= 2; }
     if (const int e = diag_env("STG_TEAM_V1", 0)) v1 = e;
     if (const int e = diag_env("STG_TEAM_V2", 0)) v2 = e;
-    (void)N;
     if (v1 > 32) v1 = 32;
     if (v2 > 64) v2 = 64;
     if (v2 < v1) v2 = v1;
     // (the backward's column-mode block needs D = [C][T][v] of the dead image, not the LDS arrays of bwd6_region_floats)
     auto region = [&](int v) { return fwd6_region_floats(v); };
-    (void)fwd;
     int r = 4 * region(v1 < V ? v1 : V);
     if (2 * region(v2 < V ? v2 : V) > r) r = 2 * region(v2 < V ? v2 : V);
     if (region(V) > r) r = region(V);
     g->on = 1; g->v1 = v1; g->v2 = v2; g->region_floats = (r + 15) & ~15;
     return true;
+}
+// beyond 32 pedestrians always; up to 32 when the batch is small enough for finer teams to pay
+static bool team_wanted(int N, int V, bool uniform, TeamGeom *g) {
+    if (!team_geom(N, V, uniform, g)) return false;
+    return V > 16 * kF6Tiles / C || g->v1 < V || diag_env("STG_TEAM", 0) != 0;
 }
 static int team_grid(size_t lds_bytes, int N) {
     int per_cu = (int)(kLdsBytes / lds_bytes);
@@ -1676,8 +1691,7 @@ static int team_grid(size_t lds_bytes, int N) {
 
 int launch_txp_fwd_wave(const TxpFwdArgs &a0, hipStream_t st) {
     TxpFwdArgs a = a0;
-    if (a.wpf && txp_fwd_x6_fits(a.lay, a.V) && (a.V > 16 * kF6Tiles / C || diag_env("STG_TEAM", 0)) &&
-        team_geom(a.N, a.V, true, &a.team)) {
+    if (a.wpf && txp_fwd_x6_fits(a.lay, a.V) && team_wanted(a.N, a.V, a.num_peds == nullptr, &a.team)) {
         const size_t lds = ((size_t)a.team.region_floats + 4 * team_ptab_floats() + 2 * kXrFwd + wave_param_floats(a.lay)) * sizeof(float);
         STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "txp_fwd_team: V=%d needs %zu bytes of LDS", a.V, lds);
         const bool bf = (a.lay.flags & STG_OPT_BF16_STORE) != 0;
@@ -1743,8 +1757,7 @@ bool txp_bwd_x6_fits(const ModelLayout &L, int V) {
 int64_t txp_bwd_x6_wp_floats(const ModelLayout &L) { return (int64_t)(L.L + 1) * cv::kWpDwords; }
 int launch_txp_bwd_wave(const TxpBwdArgs &a0, hipStream_t st) {
     TxpBwdArgs a = a0;
-    if (a.wp && txp_bwd_x6_fits(a.lay, a.V) && (a.V > 16 * kX6Tiles / C || diag_env("STG_TEAM", 0)) &&
-        team_geom(a.N, a.V, false, &a.team)) {
+    if (a.wp && txp_bwd_x6_fits(a.lay, a.V) && team_wanted(a.N, a.V, a.num_peds == nullptr, &a.team)) {
         const size_t lds = ((size_t)a.team.region_floats + 4 * team_ptab_floats() + kXrBwdWg + wave_param_floats(a.lay)) * sizeof(float);
         STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "txp_bwd_team: V=%d needs %zu bytes of LDS", a.V, lds);
         const bool bf = (a.lay.flags & STG_OPT_BF16_STORE) != 0;

@@ -43,6 +43,7 @@ struct WgradArgs {
     const int32_t *num_peds;
     const int32_t *order;  // non-null: scenes sorted by crowd size (descending)
     const int32_t *order_peds;   // with `order`: order_peds[i] = pedestrians of scene order[i] (clamped to [0, V])
+    const int32_t *key_start;    // with `order`: key_start[k] = scenes with more than V - k pedestrians (scene_order_kernel), or null
     int serpentine;        // walk the sorted list boustrophedon (1) or with a plain stride (0)
     int N, V;
     const float *ws;       // saved planes a_0 .. a_L (position-major, interior rows with their border columns)

@@ -77,10 +77,17 @@ __device__ __forceinline__ f32x4 mma(const u32x2 (&a)[2], const u32x2 (&b)[2], c
                                                    0, 0, 0);
 }
 
-template <int CINL, bool BF>
+// image rows of a COLUMN CHUNK (a work item that is part of a larger scene): fixed widths, whatever the chunk's own --
+// the staging index arithmetic then divides by constants only
+constexpr int kChunkSW = kWgradChunkV + 2, kChunkVW = kWgradChunkV;
+
+// CH: the batch is padded beyond kWgradChunkV pedestrians, scenes may be cut into column chunks (the instantiation for
+// batches of whole scenes carries none of the chunk arithmetic: the kernel sits at its 80-register budget)
+template <int CINL, bool BF, bool CH>
 __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32_t *__restrict__ order,
                                                  const int32_t *__restrict__ order_peds,
-                                                 const int32_t *__restrict__ num_peds, int layer, unsigned char *sm, int wg,
+                                                 const int32_t *__restrict__ num_peds,
+                                                 const int32_t *__restrict__ key_start, int layer, unsigned char *sm, int wg,
                                                  int nwg) {
     const ModelLayout &L = a.lay;
     const int V = a.V, tid = threadIdx.x, lane = tid & 63;
@@ -91,19 +98,40 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     const int Vc = wgrad_image_v(V);                   // widest work item: a scene, or a <= 32-column chunk of a larger one
     const int img = image_bytes(Vc, BF);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)sm;
-    const int nch = wgrad_chunks(V), items = a.N * nch;
+    const int nch = CH ? wgrad_chunks(V) : 1;
+    // Work items: chunk c of a scene exists when the scene has more than 32 c pedestrians.  With the sorted scene list the
+    // items are COMPACT -- [chunk 0 of all N scenes | chunk 1 of the scenes with more than 32 | chunk 2 of those with more
+    // than 64 | ...], the counts come from the list's tier offsets -- so that a ragged batch padded to 57 pays for the
+    // second chunk of its few large scenes only; without the list every scene has nch item slots.
+    const bool compact = CH && order && key_start && nch > 1;
+    int items = a.N * nch;
+    if (compact) {
+        items = a.N;
+        for (int c = 1; c < nch; ++c) items += key_start[V - kWgradChunkV * c];
+    }
     const int64_t plane_off = ws_plane_off(L, V, layer), dzs_floats = dz_slot(V);
 
     f32x4 acc[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    struct Raw { int at, n, v; };
+    struct Raw { int at, n, v, chunk; };
     auto fetch = [&](int r) -> Raw {
-        Raw w{-1, 0, 0};
+        Raw w{-1, 0, 0, 0};
         w.at = walk_item(r, wg, nwg, items, order != nullptr && a.serpentine);
         if (w.at >= 0) {
-            const int si = nch > 1 ? w.at / nch : w.at;
+            int si = w.at;
+            if (compact) {
+                int cnt = a.N;
+                while (si >= cnt) {                    // (at most nch - 1 steps; the counts are wave-uniform scalar loads)
+                    si -= cnt;
+                    ++w.chunk;
+                    cnt = key_start[V - kWgradChunkV * w.chunk];
+                }
+            } else if (nch > 1) {
+                si = w.at / nch;
+                w.chunk = w.at - si * nch;
+            }
             w.n = order ? order[si] : si;
             w.v = order ? order_peds[si] : (num_peds ? num_peds[si] : V);
         }
@@ -112,9 +140,9 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     auto finish = [&](const Raw &w) -> Item {
         Item it{0, 0, 0, false, nullptr, nullptr};
         if (w.at < 0) return it;
-        const int chunk = nch > 1 ? w.at - (w.at / nch) * nch : 0;
+        const int chunk = w.chunk;
         const int vfull = w.v < 0 ? 0 : (w.v > V ? V : w.v);
-        const int nc = wgrad_chunks(vfull);            // a scene of more than 32 pedestrians is cut into equal column chunks
+        const int nc = CH ? wgrad_chunks(vfull) : 1;   // a scene of more than 32 pedestrians is cut into equal column chunks
         if (vfull == 0 || chunk >= nc) return it;
         const int wc = nc > 1 ? (vfull + nc - 1) / nc : vfull;
         it.pl = a.ws + w.n * a.ws_stride + plane_off;
@@ -140,9 +168,10 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     struct Stage { StageV v[2]; };
     auto load = [&](const Item &it, Stage &s) {
         const bool live = it.valid && !STG_SKIP(a, 64);
-        const bool whole = it.vc == it.vi;
-        // image rows: the whole scene's saved rows as they are, or the chunk's vc + 2 plane columns / vc dz columns
-        const int SWi = whole ? save_sw(it.vi, BF) : it.vc + 2, VWi = whole ? save_vw(it.vi, BF) : it.vc;
+        const bool whole = !CH || it.vc == it.vi;
+        // image rows: the whole scene's saved rows as they are, or the chunk's vc + 2 plane columns / vc dz columns in rows of
+        // the fixed chunk widths
+        const int SWi = whole ? save_sw(it.vi, BF) : kChunkSW, VWi = whole ? save_vw(it.vi, BF) : kChunkVW;
         const int SWf = save_sw(it.vi, BF), VWf = save_vw(it.vi, BF);
         const int na = live ? C * SWi * 3 : 0, nz = live ? C * VWi * 3 : 0;
 #pragma unroll
@@ -150,14 +179,16 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
             const int e = tid + u * kWavesB * 64;
             constexpr int TF = BF ? 2 : 4;             // floats per task
             int ea = e, ez = e - na;                   // quad index in the saved plane / dz array
+            bool used = true;
             if (!whole) {
                 // chunk: (row, column, quad) of the image -> the scene's saved row, shifted by the chunk's first column
-                const int ra = e / 3, qa = e - ra * 3, ha = ra / SWi, ca = ra - ha * SWi;
+                const int ra = e / 3, qa = e - ra * 3, ha = ra / kChunkSW, ca = ra - ha * kChunkSW;
                 ea = (ha * SWf + it.w0 + ca) * 3 + qa;
-                const int rz = ez / 3, qz = ez - rz * 3, hz = rz / (VWi > 0 ? VWi : 1), cz = rz - hz * VWi;
+                const int rz = ez / 3, qz = ez - rz * 3, hz = rz / kChunkVW, cz = rz - hz * kChunkVW;
                 ez = (hz * VWf + it.w0 + cz) * 3 + qz;
+                used = e < na ? ca < it.vc + 2 : cz < it.vc;          // (columns past the chunk's own are never read)
             }
-            const float *src = e < na ? it.pl + TF * ea : (e < na + nz ? it.dz + TF * ez : a.ws);
+            const float *src = !used ? a.ws : (e < na ? it.pl + TF * ea : (e < na + nz ? it.dz + TF * ez : a.ws));
             if constexpr (BF) asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(s.v[u]) : "v"(src) : "memory");
             else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(s.v[u]) : "v"(src) : "memory");
         }
@@ -166,8 +197,8 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     auto landed = [&](Stage &s) { asm volatile("s_waitcnt vmcnt(2)" : "+v"(s.v[0]), "+v"(s.v[1])::"memory"); };
     auto convert = [&](const Item &it, const Stage &s, unsigned char *buf) {
         if (!it.valid || STG_SKIP(a, 64)) return;
-        const bool whole = it.vc == it.vi;
-        const int SWa = whole ? save_sw(it.vi, BF) : it.vc + 2, VWz = whole ? save_vw(it.vi, BF) : it.vc;
+        const bool whole = !CH || it.vc == it.vi;
+        const int SWa = whole ? save_sw(it.vi, BF) : kChunkSW, VWz = whole ? save_vw(it.vi, BF) : kChunkVW;
         const int na = C * SWa * 3, nz = C * VWz * 3;
         unsigned char *dzimg = buf + image_a_recs(Vc, BF) * kRec;
         // zero border rows of the plane image (rows 0 and C + 1) and the zero record behind dz: 8-byte stores
@@ -202,9 +233,9 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     // ---- this wave's K-step of the scene staged in `buf` ------------------------------------------------------------
     auto compute = [&](const Item &it, unsigned buf_off) {
         if (!it.valid || STG_SKIP(a, 128)) return;
-        const bool whole = it.vc == it.vi;
+        const bool whole = !CH || it.vc == it.vi;
         const int vi = it.vc, npos = C * vi;           // (the K loop of a chunk is that of a scene of vc pedestrians)
-        const int SWa = whole ? save_sw(vi, BF) : vi + 2, VWz = whole ? save_vw(vi, BF) : vi;
+        const int SWa = whole ? save_sw(vi, BF) : kChunkSW, VWz = whole ? save_vw(vi, BF) : kChunkVW;
         if (32 * ks >= npos) return;
         unsigned inv = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)vi));
         while (inv * (unsigned)vi < 65536u) ++inv;
@@ -326,19 +357,20 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     }
 }
 
-template <bool BF>
+template <bool BF, bool CH>
 __global__ __launch_bounds__(kWavesB * 64, 6) void txp_wgrad_bf16_kernel(const WgradArgs a, const int32_t *__restrict__ order,
                                                                          const int32_t *__restrict__ order_peds,
-                                                                         const int32_t *__restrict__ num_peds) {
+                                                                         const int32_t *__restrict__ num_peds,
+                                                                         const int32_t *__restrict__ key_start) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
     int layer = 0;
     while (layer < a.lay.L && (int)blockIdx.x >= a.wg_begin[layer + 1]) ++layer;
     const int wg = (int)blockIdx.x - a.wg_begin[layer];
     const int nwg = a.wg_begin[layer + 1] - a.wg_begin[layer];
     if (layer == 0)
-        wgrad_bf16_layer<Cfg::T, BF>(a, order, order_peds, num_peds, layer, smb, wg, nwg);
+        wgrad_bf16_layer<Cfg::T, BF, CH>(a, order, order_peds, num_peds, key_start, layer, smb, wg, nwg);
     else
-        wgrad_bf16_layer<Cfg::P, BF>(a, order, order_peds, num_peds, layer, smb, wg, nwg);
+        wgrad_bf16_layer<Cfg::P, BF, CH>(a, order, order_peds, num_peds, key_start, layer, smb, wg, nwg);
 }
 
 }  // namespace
@@ -361,13 +393,18 @@ void wgrad_bf16_geom(WgradGeom *g, const ModelLayout &L, int V) {
 
 int launch_txp_wgrad_bf16(const WgradArgs &w, const WgradGeom &g, hipStream_t st) {
     const dim3 grid(g.grid), block(kWavesB * 64);
-    const bool bf = (w.lay.flags & STG_OPT_BF16_STORE) != 0;
-    const void *fn = bf ? reinterpret_cast<const void *>(&txp_wgrad_bf16_kernel<true>)
-                        : reinterpret_cast<const void *>(&txp_wgrad_bf16_kernel<false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
-    if (e != hipSuccess) return hip_fail(e, "txp_wgrad_bf16: hipFuncSetAttribute");
-    if (bf) hipLaunchKernelGGL(txp_wgrad_bf16_kernel<true>, grid, block, g.lds, st, w, w.order, w.order_peds, w.num_peds);
-    else hipLaunchKernelGGL(txp_wgrad_bf16_kernel<false>, grid, block, g.lds, st, w, w.order, w.order_peds, w.num_peds);
+    const bool bf = (w.lay.flags & STG_OPT_BF16_STORE) != 0, ch = w.V > kWgradChunkV;
+#define STG_LW(B, H)                                                                                                  \
+    do {                                                                                                              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_wgrad_bf16_kernel<B, H>),              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);                   \
+        if (e != hipSuccess) return hip_fail(e, "txp_wgrad_bf16: hipFuncSetAttribute");                              \
+        hipLaunchKernelGGL((txp_wgrad_bf16_kernel<B, H>), grid, block, g.lds, st, w, w.order, w.order_peds, w.num_peds, \
+                           w.key_start);                                                                              \
+    } while (0)
+    if (bf) { if (ch) STG_LW(true, true); else STG_LW(true, false); }
+    else { if (ch) STG_LW(false, true); else STG_LW(false, false); }
+#undef STG_LW
     STG_LAUNCH_CHECK("txp_wgrad_bf16");
     return STG_OK;
 }

@@ -61,52 +61,55 @@ class DeviceWindows:
 class EpochRunner:
     """Reference-style training epochs (train.py:28-79: groups of `batch_size` scenes, the closing scene forwarded but
     not in the loss) over a DeviceWindows dataset, every group ONE replay of a captured hipGraph:
-    gather (by device index) -> adj_build -> forward -> NLL -> backward -> clip/SGD.  Groups shorter than batch_size
-    (the tail of an epoch) run eagerly on the same buffers."""
+    gather (by device index) -> adj_build -> forward -> NLL -> backward -> clip/SGD.  The short group at the end of an
+    epoch has a graph of its own (captured on leading slices of the same static buffers), so an epoch is graph replays and
+    device-to-device index copies only."""
 
     def __init__(self, trainer, dataset, batch_size, v_pad=None):
         self.trainer, self.ds, self.bs = trainer, dataset, int(batch_size)
         dev = dataset.device
         self.index = torch.zeros(self.bs, device=dev, dtype=torch.int32)
+        # pedestrian slots: the dataset's largest crowd rounded up to a multiple of 4 -- rows of the adjacency are then
+        # 16-byte aligned and stg_adj_build / the aggregation kernel move them with 16-byte accesses
+        v_pad = int(v_pad) if v_pad else (dataset.v_max + 3) & ~3
         self.obs_rel, self.target, self.peds = dataset.buffers(self.bs, v_pad)
         v = self.obs_rel.shape[1]
         self.nodes = torch.empty((self.bs, dataset.t_obs, v, 2), device=dev)
         self.adj = torch.empty((self.bs, dataset.t_obs, v, v), device=dev)
-        from .trainer import group_weights
-        self.weights = group_weights(self.bs, self.bs, dev)
-        self._replay = None
+        self._replays = {}                 # group size -> (replay, index slice, loss weights)
 
-    def _pre(self):
-        self.ds.gather(self.index, out=(self.obs_rel, self.target, self.peds))
-        ops.adj_build(self.obs_rel, self.peds, out=(self.nodes, self.adj))
+    def _group(self, cnt):
+        """the captured step of a group of `cnt` scenes (cnt <= batch_size): leading slices of the static buffers"""
+        g = self._replays.get(cnt)
+        if g is None:
+            from .trainer import group_weights
+            index = self.index[:cnt]
+            obs_rel, target, peds = self.obs_rel[:cnt], self.target[:cnt], self.peds[:cnt]
+            nodes, adj = self.nodes[:cnt], self.adj[:cnt]
+            weights = group_weights(cnt, self.bs, self.ds.device)
 
-    def _capture(self):
-        self._replay = self.trainer.capture(self.nodes.permute(0, 3, 1, 2), self.adj, self.target, self.peds, self.weights,
-                                            pre=self._pre)
+            def pre():
+                self.ds.gather(index, out=(obs_rel, target, peds))
+                ops.adj_build(obs_rel, peds, out=(nodes, adj))
+            replay = self.trainer.capture(nodes.permute(0, 3, 1, 2), adj, target, peds, weights, pre=pre)
+            # (the graph reads `weights` at every replay: it must stay alive with the graph)
+            g = self._replays[cnt] = (replay, index, weights)
+        return g
 
     def train_epoch(self, order):
         """order: int32 device tensor, a permutation (or any list) of window indices.  Returns the epoch loss as
         train() reports it (sum of group losses / scenes seen), accumulated on the device."""
-        from .trainer import group_bounds, group_weights
+        from .trainer import group_bounds
         self.trainer.model.train()
         n_scenes = order.numel()
         total = torch.zeros((), device=self.ds.device)
         lo = 0
         for b in group_bounds(n_scenes, self.bs):
             cnt = b + 1 - lo
-            if cnt == self.bs:
-                if self._replay is None:
-                    self.index.copy_(order[lo:b + 1])
-                    self._capture()
-                self.index.copy_(order[lo:b + 1])               # device -> device
-                out = self._replay()
-                total = total + out[0]
-            else:                                                # tail group: eager, on slices of the same buffers
-                idx = order[lo:b + 1].contiguous()
-                obs_rel, target, peds = self.ds.gather(idx, v_pad=self.obs_rel.shape[1])
-                nodes, adj = ops.adj_build(obs_rel, peds)
-                w = group_weights(cnt, self.bs, self.ds.device)
-                t, _, _ = self.trainer.step(nodes.permute(0, 3, 1, 2), adj, target, peds, w)
-                total = total + t
+            if cnt not in self._replays:
+                self.index[:cnt].copy_(order[lo:b + 1])         # (valid window indices while the group is captured)
+            replay, index, _ = self._group(cnt)
+            index.copy_(order[lo:b + 1])                        # device -> device
+            total = total + replay()[0]
             lo = b + 1
         return total / n_scenes

@@ -48,7 +48,8 @@ def test_device_gather_is_bit_equal_to_the_host_collation(eth_train):
 
 def test_captured_device_epoch_equals_the_reference_epoch(eth_train):
     """The reference's train() epoch over eth/train in dataset order (batch_size 512, fixture eth_train_epoch.npz)
-    through EpochRunner: five captured replays + one eager tail group, indices refreshed on the device."""
+    through EpochRunner: five replays of the captured 512-scene group + one of the captured tail group, indices refreshed
+    on the device."""
     from social_stgcnn_amd.dataset import DeviceWindows, EpochRunner
     from social_stgcnn_amd.model import social_stgcnn
     from social_stgcnn_amd.trainer import Trainer
@@ -75,7 +76,29 @@ def test_captured_device_epoch_equals_the_reference_epoch(eth_train):
         if err > 1e-3 * scale + 2e-7:
             bad[k] = (err, scale)
     assert not bad, bad
-    # a shuffled second epoch runs from the same captured graph
-    order2 = ds.shuffled_order(torch.Generator(device=dev).manual_seed(1))
-    assert sorted(order2.cpu().tolist()) == list(range(len(ds)))
-    assert np.isfinite(float(runner.train_epoch(order2)))
+    # a shuffled second and third epoch run from the same captured graphs (one per group size) and must equal the same
+    # epochs stepped eagerly, group by group (everything a graph reads -- indices, loss weights -- is still what it was
+    # captured with)
+    from social_stgcnn_amd import ops
+    from social_stgcnn_amd.trainer import group_bounds, group_weights
+    bs = int(g["batch_size"])
+    m2 = social_stgcnn(**CFG)
+    m2.load_state_dict({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    m2.to(dev).train()
+    tr2 = Trainer(m2, lr=float(g["lr"]))
+    gen = torch.Generator(device=dev).manual_seed(1)
+    for _ in range(2):
+        order2 = ds.shuffled_order(gen)
+        assert sorted(order2.cpu().tolist()) == list(range(len(ds)))
+        ep_graph = float(runner.train_epoch(order2))
+        lo, tot = 0, 0.0
+        for b in group_bounds(len(ds), bs):
+            idx = order2[lo:b + 1].contiguous()
+            obs_rel, target, peds = ds.gather(idx, v_pad=runner.obs_rel.shape[1])
+            nodes, adj = ops.adj_build(obs_rel, peds)
+            t, _, _ = tr2.step(nodes.permute(0, 3, 1, 2), adj, target, peds, group_weights(b + 1 - lo, bs, dev))
+            tot += float(t)
+            lo = b + 1
+        assert abs(ep_graph - tot / len(ds)) < 1e-6, (ep_graph, tot / len(ds))
+    for (k, a), (_, b2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert float((a.float() - b2.float()).abs().max()) < 1e-5, k

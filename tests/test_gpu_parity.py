@@ -543,28 +543,29 @@ def test_large_v_and_workgroup_path(dev, v, force_generic, monkeypatch):
 
 
 @pytest.mark.auto_path
-@pytest.mark.parametrize("n", (3, 200, 700))
-def test_small_batches_take_the_workgroup_path_by_themselves(dev, n):
-    """Default path selection (no option set): a small batch runs the workgroup-per-scene kernels with 8 / 4 waves per
-    scene; forward, loss and every gradient must equal the wave-per-scene result of the same batch."""
+@pytest.mark.parametrize("n,v", [(3, 12), (200, 12), (700, 12), (200, 30), (500, 30), (3, 57)])
+def test_small_batches_are_cut_into_finer_teams_by_themselves(dev, n, v):
+    """Default path selection (no option set): a small batch runs the team launch of the exact-bf16 kernels with finer
+    class bounds (fewer than 384 scenes: one wave up to 8 pedestrians, two up to 16, four beyond; fewer than 1536: 16 / 32);
+    forward, loss, every gradient and the BatchNorm buffers must equal the workgroup-per-scene kernels' result of the same
+    batch (a different kernel family: fp32 MFMA, the whole scene in one workgroup)."""
     from social_stgcnn_amd import ops
     from social_stgcnn_amd.metrics import bivariate_loss
     assert not ops.OPTIONS["wave_path"] and not ops.OPTIONS["wg_path"]
-    v = 12
     rel = torch.from_numpy(np.stack([_synthetic_scene(v, 7 + i) for i in range(8)])).to(dev)
     rel = rel[torch.arange(n, device=dev) % 8] * (1.0 + 0.001 * torch.arange(n, device=dev)[:, None, None, None])
     peds = torch.tensor([(i * 5) % v + 1 for i in range(n)], dtype=torch.int32, device=dev)
     nodes, adj = ops.adj_build(rel[..., :8], peds)
     tgt = rel[..., 8:].permute(0, 3, 1, 2).contiguous()
     res = []
-    for wave in (False, True):
-        ops.OPTIONS["wave_path"] = wave
+    for wg in (False, True):
+        ops.OPTIONS["wg_path"] = wg
         m = _model(dev, seed=5).train()
         y, _ = m(nodes.permute(0, 3, 1, 2), adj, peds)
         bivariate_loss(y.permute(0, 2, 3, 1), tgt, peds).sum().backward()
         res.append((y.detach(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
                     {k: b.clone() for k, b in m.named_buffers()}))
-    ops.OPTIONS["wave_path"] = False
+    ops.OPTIONS["wg_path"] = False
     (ya, ga, ba), (yw, gw, bw) = res
     assert float((ya - yw).abs().max()) < 2e-5
     errs = _grad_errors(((k, ga.get(k)) for k in gw), lambda name: gw[name].cpu().numpy())
