@@ -54,7 +54,7 @@ def parse_args(argv=None):
     ap.add_argument("--ragged", choices=("shuffled", "sorted"), default=None,
                     help="ragged batch: pedestrians per scene drawn from the eth/train histogram (padded to the "
                          "largest draw); 'sorted' orders the scenes by crowd size")
-    ap.add_argument("--dataset", choices=("synthetic", "eth-train"), default="synthetic",
+    ap.add_argument("--dataset", choices=("synthetic", "eth-train", "all-train"), default="synthetic",
                     help="eth-train: real ragged windows of tests/golden/data/eth_train (BASELINE configs[1])")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="bf16: bf16 STORAGE of saved activations / hand-offs (fp32 accumulate, fp32 parameters)")
@@ -71,7 +71,10 @@ def parse_args(argv=None):
     ap.add_argument("--kernels-only", action="store_true",
                     help="of the extra legs keep only the per-kernel device times (roofline); no pipeline / epoch / HBM kernels")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="seconds the self-launched ranks of --gpus N may take before the parent stops them")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--probe-fds", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
@@ -79,23 +82,65 @@ def parse_args(argv=None):
 # self-launch: N ranks as child processes, before this process touches the GPU
 # ------------------------------------------------------------------------------------------
 def launch_ranks(args):
+    """N ranks as FRESH child processes of a parent that never touches the GPU.  The children are supervised: the first
+    one that exits non-zero takes the others down (SIGTERM, then SIGKILL) and the parent exits non-zero with the tail of
+    the failing rank's stderr -- a rank that dies during RCCL initialisation must not leave its peers waiting in
+    init_process_group until the caller's time limit."""
     import socket
-    with socket.socket() as s:
+    import tempfile
+    import torch
+    backend = os.environ.get("STG_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()                     # (counts devices without initialising the GPU runtime)
+    if backend == "nccl" and args.gpus > n_dev:
+        raise SystemExit("bench.py: --gpus %d over RCCL needs %d visible GPUs, found %d (STG_DIST_BACKEND=gloo rehearses "
+                         "several ranks on one GPU)" % (args.gpus, args.gpus, n_dev))
+    with socket.socket() as s:                            # (a free port now; the ranks bind it a moment later)
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, errs = [], []
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        err = tempfile.TemporaryFile(mode="w+")
+        errs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    if any(codes):
-        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=err, text=True))
+    out0 = []
+    import threading
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()                                        # (rank 0's pipe is drained while the parent polls)
+    deadline = time.monotonic() + args.launch_timeout
+    failed = None
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = (bad[0], "exit code %d" % codes[bad[0]])
+        elif all(c == 0 for c in codes):
+            break
+        elif time.monotonic() > deadline:
+            failed = (next(r for r, c in enumerate(codes) if c is None), "still running after %.0f s" % args.launch_timeout)
+        else:
+            time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        r, why = failed
+        errs[r].seek(0)
+        tail = errs[r].read()[-2000:]
+        sys.stderr.write("bench.py: rank %d of %d failed (%s); the other ranks were stopped.\n--- rank %d stderr (tail) ---\n%s\n"
+                         % (r, args.gpus, why, r, tail))
         raise SystemExit(1)
-    sys.stdout.write(out0)
+    reader.join(10)
+    sys.stdout.write(out0[0] if out0 else "")
     return 0
 
 
@@ -141,13 +186,25 @@ def ragged_counts(n, seed, order="shuffled"):
     return c
 
 
-def eth_train_batches(n, n_batches, seed):
-    """n_batches batches of n real eth/train windows (seeded shuffle of the 2,785 windows, like the reference's
-    DataLoader(shuffle=True)), each padded to ITS largest crowd: (obs_rel (N,V,2,8), target (N,P,V,2), counts)."""
+def real_windows(which):
+    """the scene-windows of a real dataset: "eth-train" = the reference's datasets/eth/train (2,785 windows; BASELINE
+    configs[1]); "all-train" = the five leave-one-out ETH/UCY train sets concatenated (11,889 windows; BASELINE configs[2]),
+    built from the eight recordings committed under tests/golden/data."""
+    from social_stgcnn_amd import data
+    gd = os.path.join(ROOT, "tests", "golden", "data")
+    if which == "eth-train":
+        return data.load_windows(os.path.join(gd, "eth_train"), T_OBS, T_PRED, 1, with_non_linear=False)
+    splits = data.load_train_splits([os.path.join(gd, "eth_train"), os.path.join(gd, "train_extra")], obs_len=T_OBS,
+                                    pred_len=T_PRED)
+    return data.concat_windows([splits[k] for k in ("eth", "hotel", "univ", "zara1", "zara2")])
+
+
+def eth_train_batches(n, n_batches, seed, which="eth-train"):
+    """n_batches batches of n real windows (seeded shuffle of the dataset, like the reference's DataLoader(shuffle=True)),
+    each padded to ITS largest crowd (rounded up to 4): (obs_rel (N,V,2,8), target (N,P,V,2), counts)."""
     import numpy as np
     from social_stgcnn_amd import data
-    win = data.load_windows(os.path.join(ROOT, "tests", "golden", "data", "eth_train"), T_OBS, T_PRED, 1,
-                            with_non_linear=False)
+    win = real_windows(which)
     perm = np.random.default_rng(seed).permutation(len(win))
     out = []
     for b in range(n_batches):
@@ -241,19 +298,50 @@ def cpu_worker_loop(v, budget_s, seed, counts=None):
     return done, time.perf_counter() - t0
 
 
+def host_cores():
+    """cores this job may use: the affinity mask, cut down to the cgroup's CPU quota where there is one"""
+    n = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baselines(v, budget_s, counts=None):
     done, dt = cpu_worker_loop(v, budget_s, 1, counts)
     one = {"value": done / dt, "unit": "scene-windows/s", "cores": 1, "kind": "port",
            "sample": "%d scene-windows (V=%s, N=1 per forward like train.py:36-77) in %.1f s, oracle on torch CPU ops, "
                      "1 thread" % (done, v if counts is None else "ragged", dt)}
-    avail = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    # torch's autograd engine opens the GPU device node even for CPU-only work, and the GPU box admits at most 6
-    # processes with the device open: this process + 4 workers stays inside that bound (the workers scale linearly:
-    # they share nothing)
-    cores = min(avail, 4)
+    avail = host_cores()
+    # the workers are fresh children that never need the GPU: it is HIDDEN from them (torch's autograd engine would
+    # otherwise open the device node even for CPU work, and the GPU box admits only a few processes holding it), so
+    # "all cores" means all cores the box gives this job (they share nothing and scale linearly)
+    hidden = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
+                  CUDA_VISIBLE_DEVICES="")
+    # (the visibility variables alone do not keep torch's ROCm runtime from opening the device node: oracle/nogpu_shim.c,
+    # preloaded into the workers only, makes the node look absent.  A probe worker checks that it holds no device node
+    # before all the workers start; otherwise stay inside the box's bound of processes holding the GPU.)
+    shim = os.path.join(ROOT, "oracle", "libnogpu_shim.so")
+    clean = False
+    if os.path.exists(shim):
+        hidden["LD_PRELOAD"] = (shim + " " + os.environ.get("LD_PRELOAD", "")).strip()
+        try:
+            probe = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", "0", "--peds", "2",
+                                    "--cpu-seconds", "0.2", "--probe-fds"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                   text=True, env=hidden, timeout=300)
+            clean = probe.returncode == 0 and probe.stdout.strip().endswith("no-device-node")
+        except (OSError, subprocess.SubprocessError):
+            clean = False
+    cores = min(avail, 64) if clean else min(avail, 4)
+    if not clean:
+        hidden.pop("LD_PRELOAD", None)
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--peds", str(v),
-                               "--cpu-seconds", str(budget_s)], stdout=subprocess.PIPE, text=True,
-                              env=dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1"))
+                               "--cpu-seconds", str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                              text=True, env=hidden)
              for i in range(cores)]
     tot, tmax = 0, 0.0
     for p in procs:
@@ -266,9 +354,10 @@ def cpu_baselines(v, budget_s, counts=None):
             pass
     many = {"value": tot / tmax if tmax > 0 else None, "unit": "scene-windows/s", "cores": cores, "kind": "port",
             "host_cores_available": avail,
-            "sample": "%d scene-windows by %d single-threaded worker processes (data parallel over scenes like the GPU "
-                      "path; capped at 4 by the GPU box's limit of 6 processes holding the device, which torch's "
-                      "autograd engine opens even for CPU work; %d cores available) in %.1f s" % (tot, cores, avail, tmax)}
+            "sample": "%d scene-windows by %d single-threaded worker processes%s (data parallel over scenes like the "
+                      "GPU path; %d cores available to this job) in %.1f s"
+                      % (tot, cores, " with the GPU hidden from them" if clean else
+                         ", capped at 4: they could not be kept from opening the GPU device node", avail, tmax)}
     return one, many
 
 
@@ -278,6 +367,16 @@ def main():
     if args.cpu_worker >= 0:                  # child of cpu_baselines(): never touches the GPU
         d, t = cpu_worker_loop(args.peds, args.cpu_seconds, 100 + args.cpu_worker)
         print(d, t)
+        if args.probe_fds:                    # does this process hold a GPU device node after a backward pass?
+            held = []
+            for fd in os.listdir("/proc/self/fd"):
+                try:
+                    tgt = os.readlink("/proc/self/fd/" + fd)
+                except OSError:
+                    continue
+                if tgt == "/dev/kfd" or tgt.startswith("/dev/dri/"):
+                    held.append(tgt)
+            print("holds %s" % held if held else "no-device-node")
         return 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -296,9 +395,13 @@ def main():
         # RCCL ("nccl") over xGMI on a real node; STG_DIST_BACKEND=gloo lets several ranks share ONE GPU to rehearse
         # the multi-rank code path on a single-GPU box
         backend = os.environ.get("STG_DIST_BACKEND", "nccl")
-        local = local % max(1, torch.cuda.device_count())
+        n_dev = max(1, torch.cuda.device_count())
+        if backend == "nccl" and world > n_dev:
+            raise SystemExit("bench.py: %d RCCL ranks need %d visible GPUs, found %d" % (world, world, n_dev))
+        local = local % n_dev                      # (several gloo ranks may share one GPU: the one-GPU rehearsal)
         torch.cuda.set_device(local)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -317,8 +420,9 @@ def main():
     n, v = args.batch, args.peds
     n_sets = 2                                  # input batches that alternate from step to step
     sets, n_windows = [], None
-    if args.dataset == "eth-train":
-        raw, n_windows = eth_train_batches(n, n_sets, seed=1 + rank)
+    real = args.dataset in ("eth-train", "all-train")
+    if real:
+        raw, n_windows = eth_train_batches(n, n_sets, seed=1 + rank, which=args.dataset)
         for obs_rel, target, counts in raw:
             sets.append((obs_rel, target, counts))
     else:
@@ -396,10 +500,12 @@ def main():
             per_scene += [d["v"]] * n if counts is None else [int(c) for c in counts]
         all_flops = sum(flops_per_window(c) for c in per_scene) / len(per_scene)
         all_bytes = sum(bytes_per_window(c) for c in per_scene) / len(per_scene)
-        if args.dataset == "eth-train":
-            workload = ("REAL eth/train scene-windows (BASELINE configs[1]: %d of the %d windows per batch, seeded shuffle, "
-                        "2..57 pedestrians, mean %.1f, padded to %d), obs 8 / pred 12, batch %d per GPU, %s"
-                        % (n, n_windows, float(np.mean(per_scene)), max(d["v"] for d in dsets), n, args.dtype))
+        if real:
+            what = ("eth/train scene-windows (BASELINE configs[1]" if args.dataset == "eth-train" else
+                    "ETH/UCY scene-windows, the five leave-one-out train sets concatenated (BASELINE configs[2]")
+            workload = ("REAL %s: %d of the %d windows per batch, seeded shuffle, 2..57 pedestrians, mean %.1f, padded to "
+                        "%d), obs 8 / pred 12, batch %d per GPU, %s"
+                        % (what, n, n_windows, float(np.mean(per_scene)), max(d["v"] for d in dsets), n, args.dtype))
         elif args.ragged:
             workload = ("synthetic ragged scene-windows, pedestrians per window drawn from the eth/train histogram "
                         "(mean %.1f, max %d, %s order), obs 8 / pred 12, batch %d per GPU, %s"
@@ -412,7 +518,7 @@ def main():
             "value": value, "unit": "scene-windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.dtype == "f32" else "bf16-storage (fp32 accumulate, fp32 parameters)",
-            "data": "real (eth/train)" if args.dataset == "eth-train" else "synthetic",
+            "data": ("real (%s)" % args.dataset) if real else "synthetic",
             "launch": "eager" if args.no_graph else "hipGraph replay",
             "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "ms_per_step_median": ms_step,
                        "ms_per_step_p10": p10, "ms_per_step_p90": p90, "ms_per_step_first_block": first / args.steps * 1e3,
@@ -456,7 +562,7 @@ def main():
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
             if (os.path.exists(tpath) and args.dataset == "synthetic" and not args.ragged and (v, n) == (32, 2048)
-                    and args.dtype == "f32" and not args.f32_mfma and not args.wg_path):
+                    and args.dtype == "f32" and not args.f32_mfma and not args.wg_path and not real):
                 with open(tpath) as f:
                     tj = json.load(f)
                 key = dom["kernel"].split(" ")[0]
@@ -497,11 +603,9 @@ def main():
                                    "unit": "scene-windows/s"}
 
     # ---- real-data epochs from the device-resident dataset (N1): gather by device index inside the captured step ----
-    if args.dataset == "eth-train" and not args.no_extras and not args.kernels_only and not args.no_graph and world == 1:
-        from social_stgcnn_amd import data
+    if real and not args.no_extras and not args.kernels_only and not args.no_graph and world == 1:
         from social_stgcnn_amd.dataset import DeviceWindows, EpochRunner
-        win = data.load_windows(os.path.join(ROOT, "tests", "golden", "data", "eth_train"), T_OBS, T_PRED, 1,
-                                with_non_linear=False)
+        win = real_windows(args.dataset)
         ds = DeviceWindows(win, dev)
         # from the seeded initial weights again: thousands of timed steps on two fixed batches leave an over-fitted model
         # whose correlation output can saturate on unseen windows (rho = +-1 -> a NaN loss, like the reference's)
@@ -519,7 +623,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out["epoch"] = {"what": "reference-style training epochs (train.py:28-79 group semantics, batch_size %d) over the "
-                                "%d real eth/train windows resident in HBM: device shuffle, gather by device index, "
+                                "%d real windows resident in HBM: device shuffle, gather by device index, "
                                 "adjacency build, step -- ONE captured hipGraph per group, no host->device traffic in "
                                 "the loop" % (n, len(ds)),
                         "epochs": n_ep, "seconds_per_epoch": dt / n_ep, "value": n_ep * len(ds) / dt,

@@ -36,7 +36,7 @@ extern "C" {
 #define STG_EUNSUPPORTED (-2) /* configuration outside what the kernels are built for      */
 #define STG_ELDS (-3)        /* scene too large for the 160 KiB LDS of one CU             */
 
-#define STG_ABI_VERSION 6
+#define STG_ABI_VERSION 7
 #define STG_MAX_BLOCKS 4     /* st_gcn blocks in one fused model                          */
 
 int stg_abi_version(void);
@@ -262,11 +262,14 @@ int stg_gather_windows(const float *seq_rel_all, const int32_t *win_start, const
  *                 after this rank's stg_bn_fold.  pack holds n_params + world * (n_buffers + 1) floats.
  *   (the caller all-reduces `pack` with SUM over the ranks: RCCL on MI355X)
  *   stg_dp_fold : buffers = bn_before * keep^{sum_r n_r} + sum_r acc_r * keep^{sum_{j>r} n_j}, keep = 1 - momentum;
- *                 the first n_params floats of `pack` are the summed gradient (feed them to stg_optim_step).         */
+ *                 the first n_params floats of `pack` are the summed gradient (feed them to stg_optim_step).
+ *                 nbt (HOST array of n_bn DEVICE pointers to the int64 num_batches_tracked counters, may be NULL): each
+ *                 counter, already advanced by this rank's own scenes (stg_bn_fold), also receives the scene counts of
+ *                 the OTHER ranks from the pack -- afterwards every rank holds the single-process value.              */
 int stg_dp_pack(const float *grads, const float *bn_before, const float *bn_after, const int32_t *num_peds, int N,
                 float momentum, int rank, int world, int n_params, int n_buffers, float *pack, void *stream);
-int stg_dp_fold(const float *pack, const float *bn_before, float momentum, int world, int n_params, int n_buffers,
-                float *buffers, void *stream);
+int stg_dp_fold(const float *pack, const float *bn_before, float momentum, int rank, int world, int n_params,
+                int n_buffers, float *buffers, int64_t *const *nbt, int n_bn, void *stream);
 /* out[0] = sum_n weights[n] * values[n] (weights NULL: plain sum), fixed summation order: the reported group loss of
  * train.train (train.py:58-67,76) from the per-scene losses of stg_nll_fwd.                                          */
 int stg_weighted_sum(const float *values, const float *weights, int N, float *out, void *stream);

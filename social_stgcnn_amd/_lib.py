@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 # library reads no environment variable itself
 DIAG = os.environ.get("STG_USE_DIAG_LIB", "0") not in ("", "0")
 LIB_PATH = os.path.join(CSRC, "libstgcnn_hip_diag.so" if DIAG else "libstgcnn_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 OPT_WG_PATH, OPT_SPLIT_BF16, OPT_WAVE_PATH, OPT_BF16_STORE, OPT_F32_MFMA = 1, 2, 4, 8, 16
 EUNSUPPORTED = -2            # STG_EUNSUPPORTED
 
@@ -69,7 +69,7 @@ _SIGNATURES = {
                                c_f, c_f, c_f]),
     "stg_gather_windows": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
     "stg_dp_pack": (c_i, [c_f, c_f, c_f, c_f, c_i, ctypes.c_float, c_i, c_i, c_i, c_i, c_f, c_f]),
-    "stg_dp_fold": (c_i, [c_f, c_f, ctypes.c_float, c_i, c_i, c_i, c_f, c_f]),
+    "stg_dp_fold": (c_i, [c_f, c_f, ctypes.c_float, c_i, c_i, c_i, c_i, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f]),
     "stg_weighted_sum": (c_i, [c_f, c_f, c_i, c_f, c_f]),
     "stg_train_tail": (c_i, [ctypes.POINTER(ModelDesc), c_f, c_f, c_i, c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_f, c_f,
                              c_f, c_f, c_f, c_l, c_f, ctypes.c_float, ctypes.c_float, c_f, c_f]),

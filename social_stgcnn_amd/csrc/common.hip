@@ -74,11 +74,19 @@ __global__ __launch_bounds__(1024) void dp_pack_kernel(const float *__restrict__
 
 // after the all-reduce: running statistics of ONE process that saw rank 0's scenes, then rank 1's, ...:
 //   before * keep^{sum n} + sum_r acc_r * keep^{sum_{j>r} n_j}
+// nbt (optional): the num_batches_tracked counters, which the forward's own fold has advanced by THIS rank's scenes, take
+// the other ranks' scene counts from the same pack -- every rank ends with the count of the one process
 __global__ __launch_bounds__(256) void dp_fold_kernel(const float *__restrict__ pack, const float *__restrict__ before,
-                                                      float momentum, int world, int n_p, int n_b,
-                                                      float *__restrict__ buffers) {
+                                                      float momentum, int rank, int world, int n_p, int n_b,
+                                                      float *__restrict__ buffers, NbtPtrs nbt) {
     const int slot = n_b + 1;
     const double keep = 1.0 - (double)momentum;
+    if ((int)threadIdx.x < nbt.n) {
+        int64_t others = 0;
+        for (int r = 0; r < world; ++r)
+            if (r != rank) others += (int64_t)(pack[n_p + (int64_t)r * slot + n_b] + 0.5f);
+        *nbt.p[threadIdx.x] += others;
+    }
     for (int k = threadIdx.x; k < n_b; k += blockDim.x) {
         double later = 0.0, acc = 0.0;               // later = scenes of the ranks behind r
         for (int r = world - 1; r >= 0; --r) {
@@ -154,12 +162,17 @@ int stg_dp_pack(const float *grads, const float *bn_before, const float *bn_afte
     return STG_OK;
 }
 
-int stg_dp_fold(const float *pack, const float *bn_before, float momentum, int world, int n_params, int n_buffers,
-                float *buffers, void *stream) {
+int stg_dp_fold(const float *pack, const float *bn_before, float momentum, int rank, int world, int n_params,
+                int n_buffers, float *buffers, int64_t *const *nbt, int n_bn, void *stream) {
     STG_REQUIRE(pack && bn_before && buffers, STG_EINVAL, "stg_dp_fold: null pointer");
-    STG_REQUIRE(world >= 1 && n_params >= 0 && n_buffers >= 0, STG_EINVAL, "stg_dp_fold: bad sizes");
+    STG_REQUIRE(world >= 1 && rank >= 0 && rank < world && n_params >= 0 && n_buffers >= 0, STG_EINVAL,
+                "stg_dp_fold: bad sizes rank=%d world=%d", rank, world);
+    STG_REQUIRE(n_bn >= 0 && n_bn <= 3 * STG_MAX_BLOCKS && (n_bn == 0 || nbt), STG_EINVAL, "stg_dp_fold: bad nbt / n_bn=%d", n_bn);
+    stg::NbtPtrs np{};
+    np.n = nbt ? n_bn : 0;
+    for (int k = 0; k < np.n; ++k) np.p[k] = nbt[k];
     hipLaunchKernelGGL(stg::dp_fold_kernel, dim3(1), dim3(256), 0, stg::as_stream(stream), pack, bn_before, momentum,
-                       world, n_params, n_buffers, buffers);
+                       rank, world, n_params, n_buffers, buffers, np);
     STG_LAUNCH_CHECK("stg_dp_fold");
     return STG_OK;
 }

@@ -121,6 +121,42 @@ def load_windows(data_dir, obs_len=8, pred_len=12, skip=1, threshold=0.002, min_
                         np.concatenate(masks, axis=0), np.asarray(nonlin), counts, max_peds)
 
 
+def concat_windows(parts):
+    """One SceneWindows holding the windows of `parts` in order (a split is the concatenation of its files' windows,
+    utils.py:116-193; BASELINE configs[2] concatenates the five splits)."""
+    return SceneWindows(np.concatenate([p.seq for p in parts], axis=0), np.concatenate([p.seq_rel for p in parts], axis=0),
+                        np.concatenate([p.loss_mask for p in parts], axis=0),
+                        np.concatenate([p.non_linear for p in parts], axis=0),
+                        np.concatenate([p.num_peds for p in parts]), max(p.max_peds_in_frame for p in parts))
+
+
+# The ETH/UCY leave-one-out protocol of the reference's datasets/<split>/train directories: eight recordings, every
+# split trains on the ones that are not its test scene (datasets/*/train, listed with `ls`).
+TRAIN_RECORDINGS = ("biwi_eth_train.txt", "biwi_hotel_train.txt", "crowds_zara01_train.txt", "crowds_zara02_train.txt",
+                    "crowds_zara03_train.txt", "students001_train.txt", "students003_train.txt", "uni_examples_train.txt")
+TRAIN_LEFT_OUT = {"eth": ("biwi_eth_train.txt",), "hotel": ("biwi_hotel_train.txt",),
+                  "univ": ("students001_train.txt", "students003_train.txt"), "zara1": ("crowds_zara01_train.txt",),
+                  "zara2": ("crowds_zara02_train.txt",)}
+
+
+def load_train_splits(dirs, splits=("eth", "hotel", "univ", "zara1", "zara2"), obs_len=8, pred_len=12, skip=1,
+                      with_non_linear=False):
+    """The train sets of `splits` built from the eight recordings found in the directories `dirs` (every recording is
+    ingested once; a window does not depend on which split it is in).  Returns {split: SceneWindows} with each split's
+    recordings in sorted order."""
+    where = {}
+    for d in dirs:
+        for name in sorted(os.listdir(d)):
+            if name in TRAIN_RECORDINGS and name not in where:
+                where[name] = d
+    missing = [r for r in TRAIN_RECORDINGS if r not in where]
+    if missing:
+        raise FileNotFoundError("train recordings not found in %s: %s" % (list(dirs), missing))
+    per_file = {r: load_windows(where[r], obs_len, pred_len, skip, with_non_linear=with_non_linear, files=[r])
+                for r in TRAIN_RECORDINGS}
+    return {s: concat_windows([per_file[r] for r in TRAIN_RECORDINGS if r not in TRAIN_LEFT_OUT[s]]) for s in splits}
+
+
 def pad_batch(windows, indices, obs_len=8, v_pad=None):
     """Collate scene-windows `indices` into padded fp32 arrays (the layout the
     device kernels consume; padded pedestrian slots are zero and masked by num_peds):

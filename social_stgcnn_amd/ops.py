@@ -526,11 +526,13 @@ def dp_pack(flat_grad, bn_before, bn_after, num_peds, n_scenes, momentum, rank, 
           "stg_dp_pack")
 
 
-def dp_fold(pack, bn_before, momentum, world, n_params, buffers):
-    """the exact sequential fold of the running statistics over the ranks from the all-reduced pack (stg_dp_fold)."""
+def dp_fold(pack, bn_before, momentum, rank, world, n_params, buffers, nbt=()):
+    """the exact sequential fold of the running statistics over the ranks from the all-reduced pack (stg_dp_fold);
+    `nbt` (the num_batches_tracked tensors) also receive the other ranks' scene counts from the pack."""
     require_gpu(pack, bn_before, buffers)
-    check(lib().stg_dp_fold(ptr(pack), ptr(bn_before), float(momentum), int(world), int(n_params), bn_before.numel(),
-                            ptr(buffers), stream_ptr()), "stg_dp_fold")
+    arr = (ctypes.c_void_p * len(nbt))(*[b.data_ptr() for b in nbt]) if len(nbt) else None
+    check(lib().stg_dp_fold(ptr(pack), ptr(bn_before), float(momentum), int(rank), int(world), int(n_params),
+                            bn_before.numel(), ptr(buffers), arr, len(nbt), stream_ptr()), "stg_dp_fold")
 
 
 def weighted_sum(values, weights=None):

@@ -256,7 +256,7 @@ class Trainer:
         rank = dist.get_rank(self.group)
         ops.dp_pack(self._flat_grad(), before, flat_b, num_peds, int(x.shape[0]), mom, rank, self.world, pack)
         dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=self.group)          # the step's ONE collective
-        ops.dp_fold(pack, before, mom, self.world, flat_p.numel(), flat_b)
+        ops.dp_fold(pack, before, mom, rank, self.world, flat_p.numel(), flat_b, model._tensors()[2])
         self._update(flat_p, pack[:flat_p.numel()])
         return total, losses, y
 
@@ -322,7 +322,7 @@ class Trainer:
             out = self.forward_backward(x, adj, target, num_peds, weights)
             ops.dp_pack(self._flat_grad(), before, flat_b, num_peds, int(x.shape[0]), mom, rank, self.world, pack)
         with torch.cuda.graph(g_b, pool=g_a.pool()):
-            ops.dp_fold(pack, before, mom, self.world, n_p, flat_b)
+            ops.dp_fold(pack, before, mom, rank, self.world, n_p, flat_b, nbt)
             self._update(flat_p, pack[:n_p])
         self._graph = (g_a, g_b)
 

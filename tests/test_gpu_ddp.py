@@ -44,10 +44,16 @@ def test_dp_pack_and_fold_kernels_equal_their_tensor_statement():
         assert torch.allclose(pk.cpu(), packs_ref[-1], rtol=1e-6, atol=1e-7)
     total_dev = torch.stack(packs_dev).sum(0)
     out = torch.empty(n_b, device=dev)
-    ops.dp_fold(total_dev, before.to(dev), m, world, n_p, out)
+    ops.dp_fold(total_dev, before.to(dev), m, 0, world, n_p, out)
     ref = fold_from_pack(torch.stack(packs_ref).sum(0), before, m, world, n_p)
     assert torch.allclose(out.cpu(), ref, rtol=1e-6, atol=1e-6)
     assert torch.allclose(out.cpu(), seq, rtol=1e-5, atol=1e-6)
+    # num_batches_tracked: rank 1's counters (advanced by its own 3 scenes) take the other ranks' counts from the pack
+    own = int((peds[1] > 0).sum())
+    nbt = [torch.tensor(own + 100 * k, dtype=torch.int64, device=dev) for k in range(3)]
+    ops.dp_fold(total_dev, before.to(dev), m, 1, world, n_p, out, nbt)
+    everyone = sum(int((p > 0).sum()) for p in peds)
+    assert [int(t) for t in nbt] == [everyone + 100 * k for k in range(3)]
     # the reported loss reduction
     v, w = torch.randn(777, generator=gen), torch.rand(777, generator=gen)
     assert abs(float(ops.weighted_sum(v.to(dev), w.to(dev))) - float((v.double() * w.double()).sum())) < 1e-4
@@ -106,8 +112,8 @@ def test_two_ranks_equal_one_rank_on_concatenated_batch(tmp_path, captured):
     got = torch.load(out_path, weights_only=True)
     for k, v in ref.items():
         if "num_batches" in k:
-            # each rank counts its own 8 forwards (the reference counts per process too)
-            assert int(got[k]) in (8, 16), k
+            # the ranks exchange their scene counts in the step's one all-reduce: the single-process count everywhere
+            assert int(got[k]) == int(v) == 16, k
             continue
         upd = float((v - got[k]).abs().max())
         scale = max(1e-6, float(v.abs().max()))

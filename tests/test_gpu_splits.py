@@ -219,3 +219,59 @@ def test_reference_train_loop_through_the_module_api(dev):
     assert not bad, bad
     # the three dead parameters keep grad None like the reference (model.py:191)
     assert model.tpcnns[4].weight.grad is None and model.prelus[4].weight.grad is None
+
+
+def test_checkpoint_round_trip_into_the_reference(dev, tmp_path):
+    """N4 on the GPU.  (a) The weights of the fixture checkpoint (written by trainer.Checkpoint, READ BY THE REFERENCE via
+    test.py:153-186 in tests/golden/make_golden_ckpt.py) on the device -> Checkpoint.record -> load_checkpoint into a
+    fresh model: V_pred on eth/test equals the in-memory model bit for bit and the reference's V_pred of that file to
+    2e-5, its ADE / FDE with the reference's seed-0 draws.  (b) Two training groups on the GPU -> record -> reload:
+    the reloaded model is the trained one, bit for bit (train.py:228-246 writer, test.py:158 reader)."""
+    import argparse
+    from social_stgcnn_amd.model import social_stgcnn
+    from social_stgcnn_amd.trainer import Checkpoint, Trainer, evaluate_ade_fde, load_checkpoint
+    g = load_golden("ckpt_roundtrip.npz")
+    win = _windows("eth_test")
+    assert np.array_equal(win.num_peds, g["num_peds"])
+    batches = [_device_batch(dev, win, np.arange(lo, min(len(win), lo + 64))) for lo in range(0, len(win), 64)]
+
+    def vpred(model):
+        model.eval()
+        got = []
+        with torch.no_grad():
+            for b, (x, adj, peds, _, _) in enumerate(batches):
+                y, _ = model(x, adj, peds)
+                y = y.permute(0, 2, 3, 1).cpu().numpy()
+                got += [y[j, :, :int(win.num_peds[b * 64 + j])] for j in range(y.shape[0])]
+        return np.concatenate(got, axis=1)
+
+    m = social_stgcnn(**CFG)
+    m.load_state_dict(_state(g, "sd/"))
+    m.to(dev)
+    d = str(tmp_path / "checkpoint" / "social-stgcnn-roundtrip")
+    assert Checkpoint(d, argparse.Namespace(dataset="eth", n_stgcnn=1, n_txpcnn=5)).record(0, m, 0.5, 0.25)
+    m2 = load_checkpoint(social_stgcnn(**CFG), d + "/val_best.pth").to(dev)
+    v1, v2 = vpred(m), vpred(m2)
+    assert np.array_equal(v1, v2)
+    err = float(np.abs(v2 - g["vpred_cat"]).max())
+    print("checkpoint round trip: max |V_pred - reference reading the same file| = %.2e" % err)
+    assert v2.shape == g["vpred_cat"].shape and err < 2e-5, err
+    torch.manual_seed(0)
+    ade, fde, per_a, per_f = evaluate_ade_fde(m2, batches, 20)
+    np.testing.assert_allclose(per_a, g["per_ped_ade"], rtol=0, atol=1e-4)
+    assert abs(ade - float(g["ade"])) < 2e-5 and abs(fde - float(g["fde"])) < 2e-5
+    # (b) train two groups, save, reload
+    m.train()
+    tr = Trainer(m, lr=0.01)
+    x, adj, peds, _, tgt = batches[0]
+    tgt = torch.from_numpy(tgt).to(dev)
+    w = torch.full((x.shape[0],), 1.0 / x.shape[0], device=dev)
+    for _ in range(2):
+        tr.step(x, adj, tgt, peds, w)
+    ck = Checkpoint(str(tmp_path / "checkpoint" / "trained"), argparse.Namespace(dataset="eth"))
+    assert ck.record(0, m, 0.1, 0.2) and not ck.record(1, m, 0.1, 0.3)
+    m3 = load_checkpoint(social_stgcnn(**CFG), ck.dir + "/val_best.pth").to(dev)
+    for (k, a), (_, b3) in zip(m.state_dict().items(), m3.state_dict().items()):
+        assert torch.equal(a, b3), k
+    assert int(m3.state_dict()["st_gcns.0.tcn.0.num_batches_tracked"]) == 1234 + 2 * x.shape[0]
+    assert np.array_equal(vpred(m), vpred(m3))

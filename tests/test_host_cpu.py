@@ -157,3 +157,23 @@ def test_balanced_scene_shards():
         assert sums.max() / sums.min() < 1.01, sums
         plain = np.array([counts[shard_scenes(counts, world, r, balanced=False)].sum() for r in range(world)], dtype=np.float64)
         assert sums.max() - sums.min() <= plain.max() - plain.min()
+
+
+def test_bench_rank_launcher_is_supervised():
+    """bench.py --gpus N self-launches its ranks as fresh children and supervises them: more RCCL
+    ranks than visible GPUs are refused before anything is spawned; a rank that dies (here: no GPU in this container) takes
+    the others down and the parent exits non-zero, quickly, with the failing rank's stderr."""
+    import subprocess
+    import sys
+    import time
+    if torch.cuda.device_count() > 0:
+        pytest.skip("needs a machine without GPUs: the ranks are meant to fail")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"]
+    env = {k: v for k, v in os.environ.items() if k != "STG_DIST_BACKEND"}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "visible GPUs" in (r.stderr + r.stdout)
+    t0 = time.time()
+    r = subprocess.run(cmd, env=dict(env, STG_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "failed" in r.stderr and "the other ranks were stopped" in r.stderr, r.stderr[-500:]
+    assert time.time() - t0 < 200

@@ -113,3 +113,53 @@ def test_ingest_counts_of_all_fifteen_split_directories(name):
     for part, want in zip(("train", "val", "test"), ALL_COUNTS[name]):
         w = data.load_windows(os.path.join("/root/reference/datasets", name, part), 8, 12, 1, with_non_linear=False)
         assert (len(w), int(w.num_peds.sum()), int(w.num_peds.max())) == want, (name, part)
+
+
+def test_five_train_splits_from_the_eight_recordings():
+    """BASELINE configs[2] ("all five ETH/UCY splits concatenated"): the five leave-one-out train sets built from the
+    eight recordings committed under tests/golden/data (seven in eth_train/, biwi_eth_train.txt in train_extra/) have the
+    reference's window / pedestrian / largest-crowd counts (measured with its TrajectoryDataset), 11,889
+    windows together, and the eth set is the windows of the eth/train directory itself."""
+    dirs = [os.path.join(GOLDEN, "data", "eth_train"), os.path.join(GOLDEN, "data", "train_extra")]
+    splits = data.load_train_splits(dirs)
+    for name, w in splits.items():
+        assert (len(w), int(w.num_peds.sum()), int(w.num_peds.max())) == ALL_COUNTS[name][0], name
+    assert sum(len(w) for w in splits.values()) == 11889
+    eth = data.load_windows(dirs[0], 8, 12, 1, with_non_linear=False)
+    assert np.array_equal(eth.seq_rel, splits["eth"].seq_rel) and np.array_equal(eth.num_peds, splits["eth"].num_peds)
+    allw = data.concat_windows([splits[s] for s in ("eth", "hotel", "univ", "zara1", "zara2")])
+    assert len(allw) == 11889 and allw.seq_start_end[-1][1] == allw.seq_rel.shape[0] == 121709
+
+
+def test_oracle_reproduces_the_reference_reading_this_repos_checkpoint(tmp_path):
+    """N4 fixture (tests/golden/make_golden_ckpt.py: a checkpoint written by trainer.Checkpoint, read back by the REFERENCE
+    through its test.py:153-186 flow and evaluated on eth/test): the oracle with the saved weights reproduces the
+    reference's V_pred; writing the same state again gives the same val_best.pth contents and reference-style side files."""
+    import argparse
+    import pickle
+    from social_stgcnn_amd.model import social_stgcnn
+    from social_stgcnn_amd.trainer import Checkpoint
+    g = load_golden("ckpt_roundtrip.npz")
+    state = _state(g, "sd/")
+    assert list(state.keys()) == list(O.state_dict_keys()) and int(state["st_gcns.0.tcn.0.num_batches_tracked"]) == 1234
+    w = _windows("eth_test")
+    assert np.array_equal(w.num_peds, g["num_peds"])
+    col, worst = 0, 0.0
+    with torch.no_grad():
+        for i in range(len(w)):
+            s, e = w.seq_start_end[i]
+            nodes, lap = O.seq_to_graph_np(w.seq_rel[s:e, :, :8].astype(np.float32))
+            y = O.social_stgcnn_forward(state, torch.from_numpy(nodes).unsqueeze(0).permute(0, 3, 1, 2),
+                                        torch.from_numpy(lap), False)
+            worst = max(worst, float(np.abs(y[0].permute(1, 2, 0).numpy() - g["vpred_cat"][:, col:col + (e - s)]).max()))
+            col += e - s
+    assert col == g["vpred_cat"].shape[1] and worst < 2e-5, worst
+    m = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=8, kernel_size=3, pred_seq_len=12)
+    m.load_state_dict(state)
+    d = str(tmp_path / "checkpoint" / "social-stgcnn-roundtrip")
+    assert Checkpoint(d, argparse.Namespace(dataset="eth")).record(0, m, 0.5, 0.25)
+    again = torch.load(d + "/val_best.pth", weights_only=True)
+    for k, v in state.items():
+        assert torch.equal(again[k], v) and again[k].dtype == v.dtype, k
+    with open(d + "/constant_metrics.pkl", "rb") as fp:
+        assert pickle.load(fp) == {"min_val_epoch": int(g["min_val_epoch"]), "min_val_loss": float(g["min_val_loss"])}
