@@ -298,6 +298,22 @@ def cpu_worker_loop(v, budget_s, seed, counts=None):
     return done, time.perf_counter() - t0
 
 
+def kernel_source_hash():
+    """sha1 over the kernel sources (csrc/*.hip, *.hpp, include/*.h): what a committed PMC traffic file was measured on
+    (tools/profile_all.sh stamps it); bench.py quotes the file only for the same sources."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, "social_stgcnn_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "social_stgcnn_amd", "csrc", "*.hpp")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def host_cores():
     """cores this job may use: the affinity mask, cut down to the cgroup's CPU quota where there is one"""
     n = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
@@ -559,19 +575,25 @@ def main():
             dom = max((k for k in kern if k["bound"] == "mfma"), key=lambda k: k["launch_ms"])
             bwd_ms = sum(k["launch_ms"] for k in kern if k["entry"] == "stg_model_bwd")
             bwd_fl = sum(flops_per_window(c, fwd=False) for c in per_scene) / len(dsets)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            traffic, traffic_src = None, "no PMC file for this configuration"
+            tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
             if (os.path.exists(tpath) and args.dataset == "synthetic" and not args.ragged and (v, n) == (32, 2048)
                     and args.dtype == "f32" and not args.f32_mfma and not args.wg_path and not real):
                 with open(tpath) as f:
                     tj = json.load(f)
                 key = dom["kernel"].split(" ")[0]
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                want = tj.get("_meta", {}).get("kernel_source_sha1")
+                if want == kernel_source_hash():
+                    traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/r03_pmc_traffic.json, measured on these kernel sources (sha1 %s)" % want[:12]
+                else:
+                    traffic_src = ("profiles/r03_pmc_traffic.json was measured on other kernel sources (sha1 %s): not "
+                                   "quoted; regenerate with tools/profile_all.sh" % str(want)[:12])
             out["roofline"] = {
                 "bound": "mfma", "achieved": dom["achieved_tflops"], "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom["achieved_tflops"] / PEAK_FP32_TFLOPS, "traffic": traffic,
-                "traffic_note": "HBM bytes per launch of this kernel, profiles/r02_pmc_traffic.json (rocprofv3 --pmc "
-                                "FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2; regenerate with tools/profile_all.sh)",
+                "traffic_note": "HBM bytes per launch of this kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                                "passes, FETCH x2): " + traffic_src,
                 "kernel": dom["kernel"], "launch_ms": dom["launch_ms"],
                 "algorithmic_flop_per_launch": dom["algorithmic_flop_per_launch"],
                 "issued": dom.get("issued"),

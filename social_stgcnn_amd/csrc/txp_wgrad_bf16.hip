@@ -21,6 +21,7 @@
 // bytes per lane), split and written into one of two LDS images one scene ahead of its MFMAs: one s_barrier per scene.
 #include "txp_conv_bf16.hpp"
 #include "txp_wgrad.hpp"
+#include "scene_team.hpp"
 
 namespace stg {
 
@@ -156,12 +157,13 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     // ---- staging: task e of a scene = one 16-byte quad (4 channels of a position) of the plane rows or of dz ----------
     // plane: C rows x (vi + 2) columns x 3 quads, saved [h][col][12] fp32; dz: C*vi positions x 3 quads.  At most
     // 2 tasks per thread (kWgradChunkV = 32 pedestrians: 990 tasks, 640 threads).
-    // The loads are inline assembly on purpose: hipcc drains vmcnt(0) in front of every s_barrier for the loads IT
-    // tracks, which would retire the two scenes in flight at each scene's barrier; completion is counted by hand.
-    // EVERY call issues exactly two load instructions per wave (lanes without a task, and rounds past the last scene,
-    // re-read the first bytes of the workspace), so `landed` is one fixed s_waitcnt vmcnt(2); the destination is a
-    // read-write operand, which keeps a refilled set in the registers it already had (a renamed set would be copied
-    // at the loop edge -- while its data is still in flight).
+    // The loads are plain C++ loads the compiler tracks: it waits for a set's registers with COUNTED s_waitcnt vmcnt(N) right
+    // where convert() first reads them, so the other set's loads stay in flight -- also across the scene's barrier, because
+    // that barrier is team_barrier() (s_waitcnt lgkmcnt(0) + s_barrier as one asm statement: hipcc drains vmcnt(0) in front
+    // of every s_barrier it can see, which would retire the two scenes in flight at each scene's barrier).  (Round 2 issued
+    // these loads from inline assembly with a hand-counted wait: a register with data in flight was then visible to the
+    // register allocator, and nothing but a "+v" constraint kept it from being copied early.  Same speed, no hazard.)
+    // Lanes without a task, and rounds past the last scene, re-read the first bytes of the workspace.
     // bf16 storage (BF): the saved arrays ARE the h pieces (24-byte positions, 8-byte quads); m = l = 0 and only the
     // h x h product is issued -- a task moves 8 bytes, nothing is split.
     using StageV = typename StageType<BF>::type;       // what one task fetches: 16 bytes (fp32 quad) or 8 (bf16 quad)
@@ -189,12 +191,9 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
                 used = e < na ? ca < it.vc + 2 : cz < it.vc;          // (columns past the chunk's own are never read)
             }
             const float *src = !used ? a.ws : (e < na ? it.pl + TF * ea : (e < na + nz ? it.dz + TF * ez : a.ws));
-            if constexpr (BF) asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(s.v[u]) : "v"(src) : "memory");
-            else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(s.v[u]) : "v"(src) : "memory");
+            s.v[u] = *reinterpret_cast<const StageV *>(src);
         }
     };
-    // the set's loads have landed once only the two loads of the other set are outstanding
-    auto landed = [&](Stage &s) { asm volatile("s_waitcnt vmcnt(2)" : "+v"(s.v[0]), "+v"(s.v[1])::"memory"); };
     auto convert = [&](const Item &it, const Stage &s, unsigned char *buf) {
         if (!it.valid || STG_SKIP(a, 64)) return;
         const bool whole = !CH || it.vc == it.vi;
@@ -308,18 +307,16 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     load(q1, sb);
     for (int r = 0; r < rounds; r += 2) {
         // round r: scene q0 from `sa` into image 0; refill sa with scene r + 2
-        landed(sa);
         convert(q0, sa, sm);
         load(q2, sa);
-        __builtin_amdgcn_s_barrier();
+        team_barrier();
         compute(q0, 0u);
         q0 = q1; q1 = q2; q2 = finish(nxt); nxt = fetch(r + 4);
         if (r + 1 >= rounds) break;
         // round r + 1: scene (now q0) from `sb` into image 1; refill sb with scene r + 3
-        landed(sb);
         convert(q0, sb, sm + img);
         load(q2, sb);
-        __builtin_amdgcn_s_barrier();
+        team_barrier();
         compute(q0, (unsigned)img);
         q0 = q1; q1 = q2; q2 = finish(nxt); nxt = fetch(r + 5);
     }

@@ -96,3 +96,33 @@ def test_module_surface_matches_reference_state_dict():
     m.load_state_dict({k: torch.from_numpy(np.array(w[k])) for k in w.files})
     with pytest.raises(RuntimeError):          # a CPU tensor must fail loudly, not fall back
         m.eval()(torch.zeros(1, 2, 8, 3), torch.zeros(8, 3, 3))
+
+
+def test_weight_gradient_kernel_keeps_its_loads_in_flight_and_tracked(tmp_path):
+    """Compile-only ISA check of txp_wgrad_bf16: its staging loads are issued two scenes ahead.  They
+    must be loads the COMPILER tracks (no global_load in inline assembly: a destination register with data in flight must
+    never be visible to the register allocator as if it were ready), they must survive the per-scene barrier (no
+    s_waitcnt vmcnt(0) between a staging load and the loop's s_barrier), and the kernel must not address memory through
+    flat_*."""
+    import subprocess
+    src = os.path.join(ROOT, "social_stgcnn_amd", "csrc", "txp_wgrad_bf16.hip")
+    text = open(src).read()
+    assert not re.search(r'asm[^;]*global_load', text), "staging loads must not be inline assembly"
+    out = str(tmp_path / "wgrad.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--offload-device-only", "-S",
+                           src, "-o", out])
+    lines = open(out).read().split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN3stg.*txp_wgrad_bf16_kernel.*:", l)]
+    assert len(starts) == 4
+    for st in starts:
+        end = next(i for i in range(st, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
+        body = [l.strip() for l in lines[st:end] if l.strip() and not l.strip().startswith((";", "."))]
+        assert not any(l.startswith("flat_") for l in body)
+        loads = [i for i, l in enumerate(body) if l.startswith("global_load")]
+        bars = [i for i, l in enumerate(body) if l.startswith("s_barrier")]
+        assert loads and bars
+        # a barrier with a staging load a few instructions in front of it and no full vmcnt drain in between: the load is
+        # still in flight when the workgroup meets
+        in_flight = [b for b in bars
+                     if any(0 < b - ld <= 40 and not any("vmcnt(0)" in body[k] for k in range(ld, b)) for ld in loads)]
+        assert in_flight, lines[st]
