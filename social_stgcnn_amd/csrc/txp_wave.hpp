@@ -93,6 +93,10 @@ bool use_wave_path(const ModelLayout &L, int N, int V, int *wg_waves);
 int64_t ws_tail_wp_floats(const ModelLayout &l, int V);      // model_fwd.hip: floats of the operand part of the workspace's batch tail
 int launch_txp_fwd_wave(const TxpFwdArgs &a, hipStream_t st);
 int launch_txp_bwd_wave(const TxpBwdArgs &a, hipStream_t st);
+// txp_x6.hip: the exact-bf16 kernels (one wave per scene, or the team launch) -- what the two launchers above run whenever
+// txp_fwd_x6_fits / txp_bwd_x6_fits hold and the prepared operands are there
+int launch_txp_fwd_x6(const TxpFwdArgs &a, hipStream_t st);
+int launch_txp_bwd_x6(const TxpBwdArgs &a, hipStream_t st);
 // the exact-bf16 kernels (txp_fwd_x6 / txp_bwd_x6 and their team forms): V <= kTeamMaxV
 bool txp_bwd_x6_fits(const ModelLayout &L, int V);
 bool txp_fwd_x6_fits(const ModelLayout &L, int V);
