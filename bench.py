@@ -424,14 +424,8 @@ def main():
     from social_stgcnn_amd import ops
     from social_stgcnn_amd.model import social_stgcnn
     from social_stgcnn_amd.trainer import Trainer, broadcast_module
-    ops.OPTIONS["wg_path"] = bool(args.wg_path)
-    ops.OPTIONS["f32_mfma"] = bool(args.f32_mfma)
-    ops.OPTIONS["wave_path"] = bool(args.wave_path)
-    ops.OPTIONS["wg_waves"] = int(args.wg_waves)
-    if args.dtype == "bf16":
-        if "bf16_store" not in ops.OPTIONS:
-            raise SystemExit("this build has no bf16-storage mode")
-        ops.OPTIONS["bf16_store"] = True
+    options = ops.KernelOptions(wg_path=bool(args.wg_path), f32_mfma=bool(args.f32_mfma), wave_path=bool(args.wave_path),
+                                wg_waves=int(args.wg_waves), bf16_store=args.dtype == "bf16")
 
     n, v = args.batch, args.peds
     n_sets = 2                                  # input batches that alternate from step to step
@@ -467,6 +461,7 @@ def main():
     torch.manual_seed(0)
     model = social_stgcnn(n_stgcnn=1, n_txpcnn=5, output_feat=5, seq_len=T_OBS, kernel_size=3,
                           pred_seq_len=T_PRED).to(dev).train()
+    model.options = options
     broadcast_module(model)
     init_state = {k: t.detach().clone() for k, t in model.state_dict().items()}
     trainer = Trainer(model, lr=0.01)
@@ -548,11 +543,11 @@ def main():
 
     # ---- per-kernel device time (HIP events the library records between its kernels) -> roofline ----------------
     if not args.no_extras:
-        ops.TIMER = ops.KernelTimer()
+        model.timer = ops.KernelTimer()
         for i in range(max(4, min(args.steps, 20))):
             eager(dsets[i % len(dsets)])()
         torch.cuda.synchronize()
-        timer, ops.TIMER = ops.TIMER, None
+        timer, model.timer = model.timer, None
         if rank == 0:
             vmean = float(np.mean([c * 1.0 for c in per_scene]))
             kern = []

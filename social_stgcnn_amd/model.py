@@ -126,7 +126,8 @@ class st_gcn(nn.Module):
         flat_p = self._pp.ensure(params)
         flat_b = self._pb.ensure(bufs)
         desc = ops.make_desc(1, 0, self.in_channels, self.out_channels, x.shape[2], 0, self.kt, self.residual_kind,
-                             self.use_mdn, self.training, self.tcn[0].eps, self.tcn[0].momentum)
+                             self.use_mdn, self.training, self.tcn[0].eps, self.tcn[0].momentum,
+                             options=getattr(self, "options", None))
         y = ops.fused_model(x, A, num_peds, desc, flat_p, flat_b, nbt, frozenset(), params, self)
         return y, A
 
@@ -203,6 +204,6 @@ class social_stgcnn(nn.Module):
         bn = self.st_gcns[0].tcn[0]
         desc = ops.make_desc(self.n_stgcnn, self.n_txpcnn, self.input_feat, self.output_feat, self.seq_len,
                              self.pred_seq_len, self.kt, self.st_gcns[0].residual_kind, False, self.training,
-                             bn.eps, bn.momentum)
+                             bn.eps, bn.momentum, options=getattr(self, "options", None))
         y = ops.fused_model(v, a, num_peds, desc, flat_p, flat_b, nbt, dead, params, self)
         return y, a

@@ -179,29 +179,44 @@ class FlatPack:
 #   wg_path     run the workgroup-per-scene kernels even where the wave-per-scene path fits (tests cover both)
 #   split_bf16  TXP input-gradient GEMMs on bf16 MFMAs with hi/lo-split operands (opt-in, fp32 in / out)
 #   wg_waves    0 = auto, or 1 / 2 / 4 / 8 waves per scene in the workgroup-per-scene kernels
-#   wave_path   keep the wave-per-scene kernels for small batches too (default: batches of fewer than 288 scenes of <= 40
-#               pedestrians run the workgroup kernels with 4 or 8 waves per scene -- one wave per scene would leave
-#               most of the chip's wave slots empty)
+#   wave_path   keep the wave-per-scene kernels where the library would pick the workgroup-per-scene ones for a small batch
+#               (only reachable with f32_mfma / split_bf16: the exact-bf16 kernels serve small batches with finer teams)
 #   bf16_store  bf16 storage of the saved TXP activations and of the dz hand-off (STG_OPT_BF16_STORE): fp32 forward
 #               result, ~1e-3 relative error in the TXP weight / slope gradients; wave-per-scene path only
 #   f32_mfma    the fp32-MFMA kernels where the default runs the exact bf16-pipe ones (STG_OPT_F32_MFMA): A/B measurements
-OPTIONS = {"wg_path": False, "split_bf16": False, "wg_waves": 0, "wave_path": False, "bf16_store": False, "f32_mfma": False}
+class KernelOptions(dict):
+    """The launch options of ONE model: `model.options = ops.KernelOptions(bf16_store=True)` makes that model (and the
+    Trainer / EpochRunner driving it) run with its own choices, whatever other models in the process do.  A model without
+    an `options` attribute of its own uses the process-wide defaults, `ops.OPTIONS`."""
+    DEFAULTS = {"wg_path": False, "split_bf16": False, "wg_waves": 0, "wave_path": False, "bf16_store": False,
+                "f32_mfma": False}
+
+    def __init__(self, **kw):
+        bad = set(kw) - set(self.DEFAULTS)
+        if bad:
+            raise KeyError("unknown kernel options %s" % sorted(bad))
+        super().__init__(self.DEFAULTS)
+        self.update(kw)
+
+
+OPTIONS = KernelOptions()           # process-wide defaults (models without their own `options`)
 
 
 def make_desc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, use_mdn, training,
-              eps=1e-5, momentum=0.1):
-    flags = ((_lib.OPT_WG_PATH if OPTIONS["wg_path"] else 0) | (_lib.OPT_SPLIT_BF16 if OPTIONS["split_bf16"] else 0)
-             | (_lib.OPT_WAVE_PATH if OPTIONS["wave_path"] else 0)
-             | (_lib.OPT_BF16_STORE if OPTIONS["bf16_store"] else 0)
-             | (_lib.OPT_F32_MFMA if OPTIONS["f32_mfma"] else 0))
+              eps=1e-5, momentum=0.1, options=None):
+    o = OPTIONS if options is None else options
+    flags = ((_lib.OPT_WG_PATH if o["wg_path"] else 0) | (_lib.OPT_SPLIT_BF16 if o["split_bf16"] else 0)
+             | (_lib.OPT_WAVE_PATH if o["wave_path"] else 0)
+             | (_lib.OPT_BF16_STORE if o["bf16_store"] else 0)
+             | (_lib.OPT_F32_MFMA if o["f32_mfma"] else 0))
     return ModelDesc(n_stgcnn, n_txpcnn, c_in, c_out, t_obs, t_pred, kt, residual0, 1 if use_mdn else 0,
-                     1 if training else 0, eps, momentum, flags, int(OPTIONS["wg_waves"]))
+                     1 if training else 0, eps, momentum, flags, int(o["wg_waves"]))
 
 
 class KernelTimer:
     """Per-kernel device time of the fused forward / backward entry points: HIP events recorded by the library
     itself on the launch stream between its kernels (`events` argument of stg_model_fwd / stg_model_bwd).
-    Enabled by bench.py for the roofline leg; off by default."""
+    Attached to ONE model (`model.timer = ops.KernelTimer()`, bench.py's roofline leg); no timer, no events."""
     MAX_KERNELS = 8
 
     def __init__(self):
@@ -236,9 +251,8 @@ class KernelTimer:
         return sum(self.kernel_ms(name))
 
 
-TIMER = None
-LAST_FWD_SCRATCH = None
-LAST_WS_FLOATS = 0            # diagnostics: activation workspace the last fused forward allocated (0 = inference)
+def _timer_of(holder):
+    return getattr(holder, "timer", None) if holder is not None else None
 
 
 class _FusedModel(torch.autograd.Function):
@@ -267,8 +281,7 @@ class _FusedModel(torch.autograd.Function):
             desc = ModelDesc(**fields)
         out_t = desc.t_pred if desc.n_txpcnn > 0 else desc.t_obs
         y = torch.empty((n, desc.c_out, out_t, v), device=x.device, dtype=torch.float32)
-        global LAST_WS_FLOATS
-        LAST_WS_FLOATS = 0
+        ws_floats = 0                  # (diagnostics: activation workspace this forward allocated; 0 = inference)
         ws = None
         if need_grad:
             wsf = L.stg_model_ws_floats(ctypes.byref(desc), v)
@@ -278,7 +291,7 @@ class _FusedModel(torch.autograd.Function):
             if tail < 0:
                 check(int(tail), "stg_model_ws_tail_floats")
             ws = torch.empty(n * wsf + tail, device=x.device, dtype=torch.float32)
-            LAST_WS_FLOATS = ws.numel()
+            ws_floats = ws.numel()
         stats = None
         if training:
             sf = L.stg_model_stat_floats(ctypes.byref(desc))
@@ -289,10 +302,12 @@ class _FusedModel(torch.autograd.Function):
             check(int(nscr), "stg_model_fwd_scratch_floats")
         if nscr > 0:
             scr = torch.empty(int(nscr), device=x.device, dtype=torch.float32)
-            global LAST_FWD_SCRATCH
-            LAST_FWD_SCRATCH = scr          # diagnostics only (STG_STAMPS=1 reads the stamp tail)
+        if holder is not None:
+            holder.last_ws_floats = ws_floats
+            holder._last_fwd_scratch = scr  # diagnostics only (STG_STAMPS=1 reads the stamp tail)
         sn, sc, st, sv = x.stride()
-        ev = TIMER.events("model_fwd") if TIMER is not None else None
+        timer = _timer_of(holder)
+        ev = timer.events("model_fwd") if timer is not None else None
         check(L.stg_model_fwd(ctypes.byref(desc), ptr(flat_params), ptr(flat_buffers), ptr(x), sn, sc, st, sv,
                               ptr(adj_c), a_sn, ptr(peds), n, v, ptr(y), ptr(ws), ptr(stats), ptr(scr),
                               ev.arr if ev else None, ev.n if ev else 0, stream_ptr()),
@@ -337,7 +352,8 @@ class _FusedModel(torch.autograd.Function):
         grad = torch.empty(np_, device=x.device, dtype=torch.float32)
         dx = torch.empty((n, cin, t, v), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         sn, sc, st, sv = x.stride()
-        ev = TIMER.events("model_bwd") if TIMER is not None else None
+        timer = _timer_of(ctx.holder)
+        ev = timer.events("model_bwd") if timer is not None else None
         check(L.stg_model_bwd(ctypes.byref(desc), ptr(ctx.flat_params), ptr(ctx.flat_buffers), ptr(x), sn, sc, st,
                               sv, ptr(adj_c), ctx.a_sn, ptr(peds), n, v, ptr(dy), ptr(ws), ptr(slabs), ptr(grad),
                               ptr(dx), ev.arr if ev else None, ev.n if ev else 0, stream_ptr()), "stg_model_bwd")
@@ -385,7 +401,8 @@ def backward_from_target(holder, y, target, weights=None, step=None):
     grad = torch.empty(np_, device=x.device, dtype=torch.float32)
     losses = torch.empty(n, device=x.device, dtype=torch.float32)
     sn, sc, st_, sv = x.stride()
-    ev = TIMER.events("model_bwd") if TIMER is not None else None
+    timer = _timer_of(holder)
+    ev = timer.events("model_bwd") if timer is not None else None
     total = None
     if step is None:
         rc = L.stg_model_bwd_nll(ctypes.byref(desc), ptr(flat_params), ptr(flat_buffers), ptr(x), sn, sc, st_, sv,
@@ -407,7 +424,7 @@ def backward_from_target(holder, y, target, weights=None, step=None):
                                   ev.n if ev else 0, stream_ptr())
     if rc == _lib.EUNSUPPORTED:
         if ev is not None:
-            TIMER.calls["model_bwd"].pop()
+            timer.calls["model_bwd"].pop()
         return None
     check(rc, "stg_model_bwd_nll" if step is None else "stg_model_bwd_step")
     off = 0

@@ -585,10 +585,10 @@ def test_no_grad_forward_saves_no_activations(dev):
     nodes, adj = ops.adj_build(rel[..., :8])
     x = nodes.permute(0, 3, 1, 2)
     y1, _ = m(x, adj)
-    assert ops.LAST_WS_FLOATS > 0
+    assert m.last_ws_floats > 0
     with torch.no_grad():
         y0, _ = m(x, adj)
-    assert ops.LAST_WS_FLOATS == 0
+    assert m.last_ws_floats == 0
     assert _maxdiff(y0.cpu().numpy(), y1.detach().cpu().numpy()) < 1e-6
 
 
@@ -880,3 +880,24 @@ def test_bf16_pipe_kernels_agree_with_the_fp32_mfma_kernels(dev, monkeypatch):
     for k, g in gb.items():
         scale = max(0.05 * gmax, float(g.abs().max()))
         assert float((ga[k] - g).abs().max()) <= 2e-5 * scale, (k, float((ga[k] - g).abs().max()), scale)
+
+
+def test_kernel_options_belong_to_a_model(dev):
+    """ops.KernelOptions: launch options are per model, not process state -- two models in one process, one with its own
+    options (the fp32-MFMA kernels, whose training workspace carries no prepared bf16 operands), run their own kernel
+    families side by side and agree; the process-wide defaults are untouched."""
+    from social_stgcnn_amd import ops
+    with pytest.raises(KeyError):
+        ops.KernelOptions(no_such_option=True)
+    before = dict(ops.OPTIONS)
+    rel = torch.from_numpy(np.stack([_synthetic_scene(20, 40 + i) for i in range(6)])).to(dev)
+    nodes, adj = ops.adj_build(rel[..., :8])
+    x = nodes.permute(0, 3, 1, 2)
+    m1, m2 = _model(dev, seed=3).train(), _model(dev, seed=3).train()
+    m2.options = ops.KernelOptions(f32_mfma=True, wave_path=True)
+    y1, _ = m1(x, adj)
+    y2, _ = m2(x, adj)
+    y1b, _ = m1(x, adj)
+    assert m1.last_ws_floats - m2.last_ws_floats == 5 * 24 * 64 * 4          # the operand tables of five layers
+    assert torch.equal(y1, y1b) and _maxdiff(y1.detach().cpu().numpy(), y2.detach().cpu().numpy()) < 2e-5
+    assert dict(ops.OPTIONS) == before

@@ -23,7 +23,7 @@ if os.environ.get("STAMPS_EVAL"):
 else:
     for _ in range(3): m(x, adj)
 torch.cuda.synchronize()
-scr = ops.LAST_FWD_SCRATCH
+scr = m._last_fwd_scratch
 off = ((n * 3 * 8 * v + 3) & ~3) + 4 + ((n + v + 2 + 3) & ~3)     # aggregated input, pad, scene order
 st = scr[off: off + n * 32].cpu().numpy().view(np.uint64).reshape(n, 16).astype(np.int64)
 t0 = st[:, 0].min()
