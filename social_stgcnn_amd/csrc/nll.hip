@@ -11,11 +11,12 @@ namespace stg {
 __global__ __launch_bounds__(256) void nll_fwd_kernel(
     const float *__restrict__ pred, int64_t p_sn, int64_t p_sf, int64_t p_sp, int64_t p_sv,
     const float *__restrict__ target, const int32_t *__restrict__ num_peds, const float *__restrict__ gscale,
-    int P, int V, float *__restrict__ loss, float *__restrict__ grad) {
+    int P, int V, float *__restrict__ loss, float *__restrict__ grad, int fast) {
     __shared__ float red[4];
     const int n = blockIdx.x, tid = threadIdx.x;
     int vi = num_peds ? num_peds[n] : V;
     vi = vi < 0 ? 0 : (vi > V ? V : vi);
+    (void)fast;                                        // (diagnostic builds: STG_FAST_NLL=1 measures nll_elem_t<true>)
     const float *pn = pred + n * p_sn;
     const float *tn = target + (int64_t)n * P * V * 2;
     float *gn = grad ? grad + (int64_t)n * 5 * P * V : nullptr;
@@ -28,6 +29,10 @@ __global__ __launch_bounds__(256) void nll_fwd_kernel(
         if (v < vi) {
             const float *q = pn + p * p_sp + v * p_sv;
             const float2 tg = *reinterpret_cast<const float2 *>(tn + (int64_t)e * 2);
+#ifdef STG_DIAG
+            if (fast) acc += nll_elem_t<true>(q[0], q[p_sf], q[2 * p_sf], q[3 * p_sf], q[4 * p_sf], tg.x, tg.y, gn != nullptr, g);
+            else
+#endif
             acc += nll_elem(q[0], q[p_sf], q[2 * p_sf], q[3 * p_sf], q[4 * p_sf], tg.x, tg.y, gn != nullptr, g);
         }
         if (gn) {
@@ -62,7 +67,7 @@ int stg_nll_fwd(const float *pred, int64_t p_sn, int64_t p_sf, int64_t p_sp, int
     if (N == 0) return STG_OK;
     STG_REQUIRE(pred && target && loss, STG_EINVAL, "stg_nll_fwd: null pointer");
     hipLaunchKernelGGL(stg::nll_fwd_kernel, dim3(N), dim3(256), 0, stg::as_stream(stream), pred, p_sn, p_sf, p_sp,
-                       p_sv, target, num_peds, grad_scale, P, V, loss, grad);
+                       p_sv, target, num_peds, grad_scale, P, V, loss, grad, stg::diag_env("STG_FAST_NLL", 0));
     STG_LAUNCH_CHECK("stg_nll_fwd");
     return STG_OK;
 }

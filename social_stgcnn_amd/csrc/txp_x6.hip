@@ -271,6 +271,12 @@ __device__ __forceinline__ void txp_bwd_scene_x6(const TxpBwdArgs &a, const floa
                         const float *q = dyn + (int64_t)p * V + w;
                         const float2 tg = *reinterpret_cast<const float2 *>(tn + ((int64_t)p * V + w) * 2);
                         float g[5];
+#ifdef STG_DIAG
+                        if (STG_SKIP(a, 1 << 21))       // (diagnostic builds: time the hardware-transcendental form)
+                            lacc += nll_elem_t<true>(q[0], q[(int64_t)P * V], q[(int64_t)2 * P * V], q[(int64_t)3 * P * V],
+                                                     q[(int64_t)4 * P * V], tg.x, tg.y, true, g);
+                        else
+#endif
                         lacc += nll_elem(q[0], q[(int64_t)P * V], q[(int64_t)2 * P * V], q[(int64_t)3 * P * V],
                                          q[(int64_t)4 * P * V], tg.x, tg.y, true, g);
 #pragma unroll

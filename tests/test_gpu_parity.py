@@ -148,7 +148,8 @@ def test_adj_build_batched_ragged(dev):
 
 
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,c,v,shared", [(3, 5, 32, False), (2, 2, 7, False), (4, 5, 57, True), (1, 11, 12, False)])
+@pytest.mark.parametrize("n,c,v,shared", [(3, 5, 32, False), (2, 2, 7, False), (4, 5, 57, True), (1, 11, 12, False),
+                                           (2, 5, 64, False), (3, 3, 16, False), (5, 2, 8, True), (2, 9, 32, True)])
 def test_spatial_agg(dev, n, c, v, shared):
     """R3 einsum('nctv,ntvw->nctw') forward and dx; fp32 reference = torch.einsum on the CPU, 2e-5."""
     from social_stgcnn_amd import ops
