@@ -130,6 +130,9 @@ __device__ __forceinline__ int walk_item(int r, int w, int G, int N, bool serpen
     const int i = r * G + ((serpentine && (r & 1)) ? G - 1 - w : w);
     return i < N ? i : -1;
 }
+// a scene index read from the sorted list, forced into [0, N): the backward takes the list the forward left in the
+// workspace's batch tail on trust (include/stgcnn_hip.h: the same descriptor and num_peds for both passes)
+__host__ __device__ inline int scene_index(int i, int N) { return i < 0 ? 0 : (i >= N ? N - 1 : i); }
 // V-tier of a launch: the scenes with v_lo < V_n <= v_hi, a contiguous range of the sorted list
 struct SceneTier {
     const int32_t *order;      // sorted scene list or null (then the tier is the whole batch in batch order)
@@ -143,6 +146,8 @@ __device__ __forceinline__ void tier_range(const SceneTier &t, int N, int V, int
     if (t.order && t.key_start) {
         begin = t.key_start[V - (t.v_hi > V ? V : t.v_hi)];
         end = t.key_start[V - t.v_lo];          // v_lo = -1 -> key_start[V + 1] = N
+        begin = begin < 0 ? 0 : (begin > N ? N : begin);
+        end = end < begin ? begin : (end > N ? N : end);
     }
 }
 constexpr int kOrderMaxN = 65536;      // scene_order_kernel is ONE workgroup: N/1024 scenes per lane
@@ -171,7 +176,14 @@ struct AggPrep {
     unsigned *wp_fwd;      // forward operands (the forward's scratch) or null
     int n_layers;
     int32_t w_off[kMaxTxp + 1];
+    // ragged batch: ONE more workgroup of the launch sorts the scenes by crowd size (scene_order.hpp) -- the schedule of
+    // the kernels behind it -- instead of a launch of its own; null = no sort here
+    int32_t *order, *key_start, *order_peds;
 };
+// whether the aggregation launch carries the sort: its workgroups have 4 waves (N / 4 scenes per wave), so beyond 1024
+// scenes the sorting workgroup outlasts the aggregation itself (measured at 2048: 30 us against 21) and the 16-wave
+// scene_order_kernel as a launch of its own is the cheaper way (5 us + a kernel boundary)
+inline bool agg_sorts(const int32_t *num_peds, int N, int V) { return scene_order_applies(num_peds, N, V) && N <= 1024; }
 int launch_stgcn_agg(int cin, const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv, const float *adj,
                      int64_t a_sn, const int32_t *num_peds, int N, int V, float *out, int64_t out_stride, int64_t ax_off,
                      int64_t cs_off, hipStream_t st, const AggPrep *prep = nullptr);

@@ -296,6 +296,7 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         a.agg_cs = (int64_t)b0.cin * Cfg::T * V;
     }
     a.debug_skip = diag_env("STG_DEBUG_SKIP", 0);
+    bool sorted_in_agg = false;
     {
         // training on the wave-per-scene path: the launch also prepares the backward's exact-bf16 A operands into the
         // batch tail of the workspace (stg_model_ws_tail_floats behind the N per-scene blocks)
@@ -307,9 +308,15 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         // ... and the forward's own (this launch's successor reads them from the scratch buffer)
         if (wave_path && txp_fwd_x6_fits(L, V))
             prep.wp_fwd = reinterpret_cast<unsigned *>(scratch + fwd_wp_off(L, N, V, diag_env("STG_STAMPS", 0) != 0));
+        // ... and, for a ragged batch on the wave-per-scene path, the scene order: one more workgroup of this launch
+        // (training: into the workspace's batch tail, where the backward finds it -- no second sort)
+        int32_t *order0 = reinterpret_cast<int32_t *>(scratch + fwd_agg_floats(L, N, V));
+        if (ws && wave_path) order0 = reinterpret_cast<int32_t *>(ws + (int64_t)N * a.ws_stride + ws_tail_wp_floats(L, V));
+        sorted_in_agg = wave_path && agg_sorts(num_peds, N, V);
+        if (sorted_in_agg) { prep.order = order0; prep.key_start = order0 + N; prep.order_peds = order0 + N + V + 2; }
         const int rca = launch_stgcn_agg(b0.cin, x, x_sn, x_sc, x_st, x_sv, adj, a_sn, num_peds, N, V,
                                          const_cast<float *>(a.agg), a.agg_stride, a.agg_ax, a.agg_cs, st,
-                                         (prep.wp || prep.wp_fwd) ? &prep : nullptr);
+                                         (prep.wp || prep.wp_fwd || prep.order) ? &prep : nullptr);
         if (rca != STG_OK) return rca;
     }
     evl.mark();
@@ -319,8 +326,11 @@ extern "C" int stg_model_fwd(const stg_model_desc *d, const float *params, const
         // leaves LDS.  Ragged batch: sorted scene list, walked boustrophedon.  Training: the order (with its tier offsets
         // and the sorted counts) goes to the workspace's batch tail, where the backward finds it -- no second sort.
         if (ws) order = reinterpret_cast<int32_t *>(ws + (int64_t)N * a.ws_stride + ws_tail_wp_floats(L, V));
-        const bool sorted = launch_scene_order(num_peds, N, V, order, order + N, st, order + N + V + 2);
-        if (!sorted && scene_order_applies(num_peds, N, V)) return hip_fail(hipErrorLaunchFailure, "stg_model_fwd: scene_order launch");
+        bool sorted = sorted_in_agg;                   // (sorted by a workgroup of the aggregation launch above ...)
+        if (!sorted) {                                  // (... or, for a large batch, by the 16-wave kernel)
+            sorted = launch_scene_order(num_peds, N, V, order, order + N, st, order + N + V + 2);
+            if (!sorted && scene_order_applies(num_peds, N, V)) return hip_fail(hipErrorLaunchFailure, "stg_model_fwd: scene_order launch");
+        }
         TxpFwdArgs t{};
         t.lay = L; t.params = params; t.buffers = buffers; t.num_peds = num_peds; t.N = N; t.V = V;
         t.x = x; t.x_sn = x_sn; t.x_sc = x_sc; t.x_st = x_st; t.x_sv = x_sv;

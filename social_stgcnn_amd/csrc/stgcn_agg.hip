@@ -13,6 +13,7 @@
 // the block kernels index.
 #include "model_common.hpp"
 #include "txp_conv_bf16.hpp"
+#include "scene_order.hpp"
 
 namespace stg {
 
@@ -28,10 +29,22 @@ __global__ __launch_bounds__(256) void stgcn_agg_kernel(const float *__restrict_
                                                         int64_t cs_off, AggPrep prep) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= N) {
+    int blk = (int)blockIdx.x;
+    if (prep.order) {
+        // ragged batch: workgroup 0 -- dispatched first, so it runs beside the whole launch -- sorts the scenes by crowd
+        // size (no launch of its own)
+        if (blk == 0) {
+            __shared__ int wave_tot[4];
+            scene_order_body<4>(num_peds, N, V, prep.order, prep.key_start, prep.order_peds, reinterpret_cast<int *>(sm),
+                                wave_tot);
+            return;
+        }
+        --blk;
+    }
+    if (blk >= N) {
+        int b = blk - N;
         // training: the workgroups behind the scenes prepare the A operands of the backward's exact-bf16
         // input-gradient GEMMs (one 16-byte vector per lane and block; txp_conv_bf16.hpp) -- no launch of their own
-        int b = (int)blockIdx.x - N;
         const bool fwd = b >= prep.n_layers * cv::kWpVecs;
         if (fwd) b -= prep.n_layers * cv::kWpVecs;
         const int l = b / cv::kWpVecs, v = b - l * cv::kWpVecs;
@@ -47,7 +60,7 @@ __global__ __launch_bounds__(256) void stgcn_agg_kernel(const float *__restrict_
         }
         return;
     }
-    const int n = blockIdx.x;
+    const int n = blk;
     int vi = num_peds ? num_peds[n] : V;
     vi = vi < 0 ? 0 : (vi > V ? V : vi);
     if (vi == 0) return;
@@ -124,8 +137,9 @@ int launch_stgcn_agg(int cin, const float *x, int64_t x_sn, int64_t x_sc, int64_
     if (N == 0) return STG_OK;
     AggPrep prep{};
     if (prep_in) prep = *prep_in;
-    const dim3 grid(N + ((prep.wp || prep.wp_fwd) ? 2 * prep.n_layers * cv::kWpVecs : 0)), block(256);
-    const size_t lds = (size_t)cin * T * V * sizeof(float);
+    const dim3 grid(N + (prep.order ? 1 : 0) + ((prep.wp || prep.wp_fwd) ? 2 * prep.n_layers * cv::kWpVecs : 0)), block(256);
+    size_t lds = (size_t)cin * T * V * sizeof(float);
+    if (prep.order && lds < (size_t)(V + 1) * 4 * sizeof(int)) lds = (size_t)(V + 1) * 4 * sizeof(int);   // the sort's histogram
     STG_REQUIRE(lds <= (size_t)kLdsBytes, STG_ELDS, "stgcn_agg: V=%d needs %zu bytes of LDS", V, lds);
     // 16-byte loads need 16-byte aligned rows: V a multiple of 4 and a 16-byte aligned base / batch stride
     const int min_strips = diag_env("STG_AGG_VEC_STRIPS", 256);

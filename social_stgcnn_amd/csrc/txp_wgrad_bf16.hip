@@ -108,7 +108,10 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
     int items = a.N * nch;
     if (compact) {
         items = a.N;
-        for (int c = 1; c < nch; ++c) items += key_start[V - kWgradChunkV * c];
+        for (int c = 1; c < nch; ++c) {
+            const int more = key_start[V - kWgradChunkV * c];
+            items += more < 0 ? 0 : (more > a.N ? a.N : more);
+        }
     }
     const int64_t plane_off = ws_plane_off(L, V, layer), dzs_floats = dz_slot(V);
 
@@ -128,12 +131,15 @@ __device__ __forceinline__ void wgrad_bf16_layer(const WgradArgs &a, const int32
                     si -= cnt;
                     ++w.chunk;
                     cnt = key_start[V - kWgradChunkV * w.chunk];
+                    cnt = cnt < 0 ? 0 : (cnt > a.N ? a.N : cnt);
+                    if (w.chunk >= nch - 1) break;
                 }
+                if (si >= a.N) si = a.N - 1;           // (only with a tail that is not this batch's: stay inside the list)
             } else if (nch > 1) {
                 si = w.at / nch;
                 w.chunk = w.at - si * nch;
             }
-            w.n = order ? order[si] : si;
+            w.n = order ? scene_index(order[si], a.N) : si;
             w.v = order ? order_peds[si] : (num_peds ? num_peds[si] : V);
         }
         return w;

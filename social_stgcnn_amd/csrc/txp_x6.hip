@@ -170,7 +170,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
     for (int r = 0; r * nw < M; ++r) {
         const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
         if (it < 0) continue;
-        const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
+        // (clamped: a workspace tail that does not hold THIS batch's order -- a caller's contract breach -- must not turn
+        // into an out-of-bounds scene index)
+        const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? scene_index(a.tier.order[begin + it], a.N) : it);
         int vi = a.num_peds ? a.num_peds[n] : a.V;
         vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > a.V ? a.V : vi));
         txp_fwd_scene_x6<BF>(a, params, blk_p, blk_b, n, vi, region, ptab, SoloScene{vi});
@@ -465,7 +467,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 8 ? 1 : 2) __attribute__((amdgpu_w
     for (int r = 0; r * nw < M; ++r) {
         const int it = walk_item(r, gw, nw, M, a.tier.order != nullptr && a.tier.serpentine);
         if (it < 0) continue;
-        const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? a.tier.order[begin + it] : it);
+        // (clamped: a workspace tail that does not hold THIS batch's order -- a caller's contract breach -- must not turn
+        // into an out-of-bounds scene index)
+        const int n = __builtin_amdgcn_readfirstlane(a.tier.order ? scene_index(a.tier.order[begin + it], a.N) : it);
         int vi = a.num_peds ? a.num_peds[n] : a.V;
         vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > a.V ? a.V : vi));
         txp_bwd_scene_x6<BF>(a, blk_p, n, vi, region, ptab, SoloScene{vi});
@@ -526,7 +530,7 @@ __device__ __forceinline__ TeamUnit team_unit(const SceneTier &t, const TeamCoun
     } else {
         q.nch = 1; q.slot = wave; q.ci = 0; idx = c.n4 + c.n2 + 4 * (u - c.u4 - c.u2) + wave;
     }
-    q.n = idx < N ? (c.sorted ? t.order[idx] : idx) : -1;
+    q.n = idx < N ? (c.sorted ? scene_index(t.order[idx], N) : idx) : -1;
     q.n = __builtin_amdgcn_readfirstlane(q.n);
     int vi = q.n >= 0 ? (num_peds ? num_peds[q.n] : V) : 0;
     vi = __builtin_amdgcn_readfirstlane(vi < 0 ? 0 : (vi > V ? V : vi));
