@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void spatial_agg_bwd_rows_kernel(
     constexpr int V = 4 * LPR, RPI = 256 / LPR;                      // rows per workgroup pass
     constexpr int G = (V + RPI - 1) / RPI;                           // row groups of a tile (1 up to V = 32, 4 at V = 64)
     constexpr int TB = G == 1 ? 4 : 1;                               // time steps in flight together
+    extern __shared__ __attribute__((aligned(16))) float dys[];      // [C][T][V]: dy[n], padded columns zeroed
     const int n = blockIdx.x, tid = threadIdx.x;
     int vi = num_peds ? num_peds[n] : V;
     vi = vi < 0 ? 0 : (vi > V ? V : vi);
@@ -197,6 +198,18 @@ __global__ __launch_bounds__(256) void spatial_agg_bwd_rows_kernel(
     const float *an = adj + n * a_sn;
     const int piece = tid & (LPR - 1), rsub = tid / LPR, w0 = 4 * piece;
     const bool m1 = w0 + 1 < vi, m2 = w0 + 2 < vi, m3 = w0 + 3 < vi;
+    // dy through LDS: every row of a time step needs the same 4 V bytes per channel -- as global loads (L1 hits) they cost
+    // the CU's address path five wave-instructions per adjacency instruction; as LDS reads nothing
+    for (int e = tid; e < C * T * (V / 4); e += 256) {
+        float4 q = reinterpret_cast<const float4 *>(dyn)[e];
+        const int w = (e % (V / 4)) * 4;
+        q.x = w < vi ? q.x : 0.f;
+        q.y = w + 1 < vi ? q.y : 0.f;
+        q.z = w + 2 < vi ? q.z : 0.f;
+        q.w = w + 3 < vi ? q.w : 0.f;
+        reinterpret_cast<float4 *>(dys)[e] = q;
+    }
+    __syncthreads();
     for (int t0 = 0; t0 < T; t0 += TB) {
         float4 a[TB][G];
 #pragma unroll
@@ -220,11 +233,7 @@ __global__ __launch_bounds__(256) void spatial_agg_bwd_rows_kernel(
                 a[tb][g].w = m3 ? a[tb][g].w : 0.f;
             }
             for (int c = 0; c < C; ++c) {
-                float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (w0 < vi) d = *reinterpret_cast<const float4 *>(dyn + ((int64_t)c * T + t) * V + w0);
-                d.y = m1 ? d.y : 0.f;
-                d.z = m2 ? d.z : 0.f;
-                d.w = m3 ? d.w : 0.f;
+                const float4 d = *reinterpret_cast<const float4 *>(dys + (c * T + t) * V + w0);
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const int v = g * RPI + rsub;
@@ -271,13 +280,13 @@ int stg_spatial_agg_bwd(const float *dy, const float *adj, int64_t a_sn, const i
     STG_REQUIRE(lds <= stg::kLdsBytes, STG_ELDS, "stg_spatial_agg_bwd: C*T*V=%d floats exceed LDS", C * T * V);
     const bool vec4 = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(adj) & 15) == 0) && (a_sn % 4 == 0);
     const bool aligned = vec4 && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
-    if (aligned && (V == 8 || V == 16 || V == 32 || V == 64)) {
+    if (aligned && (V == 8 || V == 16 || V == 32 || V == 64) && lds <= 64 * 1024) {
         // the coalesced form: rows shared by V / 4 lanes (measured at V = 32 on a 537 MB working set: see DESIGN 5)
         switch (V) {
-            case 8: hipLaunchKernelGGL(stg::spatial_agg_bwd_rows_kernel<2>, dim3((unsigned)N), dim3(256), 0, stg::as_stream(stream), dy, adj, a_sn, num_peds, C, T, dx); break;
-            case 16: hipLaunchKernelGGL(stg::spatial_agg_bwd_rows_kernel<4>, dim3((unsigned)N), dim3(256), 0, stg::as_stream(stream), dy, adj, a_sn, num_peds, C, T, dx); break;
-            case 32: hipLaunchKernelGGL(stg::spatial_agg_bwd_rows_kernel<8>, dim3((unsigned)N), dim3(256), 0, stg::as_stream(stream), dy, adj, a_sn, num_peds, C, T, dx); break;
-            default: hipLaunchKernelGGL(stg::spatial_agg_bwd_rows_kernel<16>, dim3((unsigned)N), dim3(256), 0, stg::as_stream(stream), dy, adj, a_sn, num_peds, C, T, dx); break;
+            case 8: hipLaunchKernelGGL(stg::spatial_agg_bwd_rows_kernel<2>, dim3((unsigned)N), dim3(256), lds, stg::as_stream(stream), dy, adj, a_sn, num_peds, C, T, dx); break;
+            case 16: hipLaunchKernelGGL(stg::spatial_agg_bwd_rows_kernel<4>, dim3((unsigned)N), dim3(256), lds, stg::as_stream(stream), dy, adj, a_sn, num_peds, C, T, dx); break;
+            case 32: hipLaunchKernelGGL(stg::spatial_agg_bwd_rows_kernel<8>, dim3((unsigned)N), dim3(256), lds, stg::as_stream(stream), dy, adj, a_sn, num_peds, C, T, dx); break;
+            default: hipLaunchKernelGGL(stg::spatial_agg_bwd_rows_kernel<16>, dim3((unsigned)N), dim3(256), lds, stg::as_stream(stream), dy, adj, a_sn, num_peds, C, T, dx); break;
         }
     } else if (vec4) {
         if (lds > 64 * 1024) {
