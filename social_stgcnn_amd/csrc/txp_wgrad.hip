@@ -305,17 +305,18 @@ bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
     g->bf16mma = wgrad_bf16_fits(L, V) && !diag_env("STG_WGRAD_F32", 0);
     if (g->bf16mma) {
         wgrad_bf16_geom(g, L, V);
-        per_cu = 2;
+        per_cu = (int)((size_t)kLdsBytes / g->lds);
     }
     int total = kNumCU * per_cu;                       // resident workgroups on the chip
     if (const int v = diag_env("STG_WGRAD_GRID", 0)) total = v > 0 ? v : total;
     const int nl = L.L + 1;
     if (total < nl) total = nl;
     const int need = N * wgrad_chunks(V);              // never more workgroups per layer than work items
-    const int wsum = 6 + 7 * (nl - 1);                 // per item: same staging bytes, 5 vs 7 column tiles of MFMAs
+    // per item: the same staging, 5 (layer 0) vs 7 column tiles of MFMAs
+    const int w0 = g->bf16mma ? 7 : 6, w1 = g->bf16mma ? 9 : 7, wsum = w0 + w1 * (nl - 1);
     int begin = 0, maxw = 0;
     for (int l = 0; l < nl; ++l) {
-        int cnt = (int)((int64_t)total * (l == 0 ? 6 : 7) / wsum);
+        int cnt = (int)((int64_t)total * (l == 0 ? w0 : w1) / wsum);
         if (cnt < 1) cnt = 1;
         if (cnt > need) cnt = need;
         g->wg_begin[l] = begin;

@@ -32,7 +32,7 @@ __host__ __device__ inline int64_t wgrad_slab_base(int layer, int rows) {
 
 struct WgradGeom {
     int waves, nbuf, grid, rows;    // rows = slab rows per layer (= the largest workgroup count of a layer)
-    bool bf16mma;                   // txp_wgrad_bf16.hip (whole-scene fp32 items) instead of txp_wgrad.hip
+    bool bf16mma;                   // txp_wgrad_bf16.hip (bf16 matrix pipe) instead of txp_wgrad.hip
     int wg_begin[kMaxTxp + 2];      // layer l owns workgroups [wg_begin[l], wg_begin[l+1])
     size_t lds;
 };

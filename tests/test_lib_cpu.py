@@ -99,7 +99,7 @@ def test_module_surface_matches_reference_state_dict():
 
 
 def test_weight_gradient_kernel_keeps_its_loads_in_flight_and_tracked(tmp_path):
-    """Compile-only ISA check of txp_wgrad_bf16: its staging loads are issued two scenes ahead.  They
+    """Compile-only ISA check of txp_wgrad_bf16: its staging loads are issued one item ahead.  They
     must be loads the COMPILER tracks (no global_load in inline assembly: a destination register with data in flight must
     never be visible to the register allocator as if it were ready), they must survive the per-scene barrier (no
     s_waitcnt vmcnt(0) between a staging load and the loop's s_barrier), and the kernel must not address memory through
@@ -118,6 +118,7 @@ def test_weight_gradient_kernel_keeps_its_loads_in_flight_and_tracked(tmp_path):
         end = next(i for i in range(st, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
         body = [l.strip() for l in lines[st:end] if l.strip() and not l.strip().startswith((";", "."))]
         assert not any(l.startswith("flat_") for l in body)
+        assert not any(l.startswith("scratch_") for l in body), "spilled registers in " + lines[st]
         loads = [i for i, l in enumerate(body) if l.startswith("global_load")]
         bars = [i for i, l in enumerate(body) if l.startswith("s_barrier")]
         assert loads and bars
