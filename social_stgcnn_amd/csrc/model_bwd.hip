@@ -362,7 +362,14 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceArgs a, c
             if (p >= g.p0 && p < g.p0 + g.len) {
                 const float *src = a.slabs + g.base + (p - g.p0);
                 int k = grp;
-                for (; k + 480 < g.rows; k += 512) {        // 16 rows in flight per lane (2048 slab rows: 4 trips)
+                for (; k + 992 < g.rows; k += 1024) {       // 32 rows in flight per lane (2048 slab rows: 2 trips)
+                    float v[32];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) v[u] = src[(int64_t)(k + 32 * u) * g.row_stride];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) s += v[u];
+                }
+                for (; k + 480 < g.rows; k += 512) {
                     float v[16];
 #pragma unroll
                     for (int u = 0; u < 16; ++u) v[u] = src[(int64_t)(k + 32 * u) * g.row_stride];
