@@ -34,10 +34,12 @@ struct SoloScene {
     template <int K>
     __device__ __forceinline__ void sum(float (&v)[K], int) const { wave_sum_n<K>(v); }
     // K per-lane values summed over this wave's part of the scene; the totals are valid in the lanes where writer() holds,
-    // which store them to row(the scene's row of small-parameter gradients)
+    // which store them to row(the scene's row of small-parameter gradients).  Lane 63 stores them where the DPP stages leave
+    // them: broadcast to every lane (v_readlane) they became SCALARS -- 142 readlanes, a v_mov per stored value and enough
+    // SGPR pressure in the backward's block tail for 516 spill reloads (v_readlane from a spill VGPR) in the ISA.
     template <int K>
-    __device__ __forceinline__ void reduce(float (&v)[K]) const { wave_sum_n<K>(v); }
-    __device__ __forceinline__ bool writer() const { return (threadIdx.x & 63) == 0; }
+    __device__ __forceinline__ void reduce(float (&v)[K]) const { wave_sum_to_last<K>(v); }
+    __device__ __forceinline__ bool writer() const { return (threadIdx.x & 63) == 63; }
     __device__ __forceinline__ float *row(float *scene_row) const { return scene_row; }
 };
 
