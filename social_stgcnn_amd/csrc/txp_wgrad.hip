@@ -312,8 +312,9 @@ bool wgrad_geom(const ModelLayout &L, int N, int V, WgradGeom *g) {
     const int nl = L.L + 1;
     if (total < nl) total = nl;
     const int need = N * wgrad_chunks(V);              // never more workgroups per layer than work items
-    // per item: the same staging, 5 (layer 0) vs 7 column tiles of MFMAs
-    const int w0 = g->bf16mma ? 7 : 6, w1 = g->bf16mma ? 9 : 7, wsum = w0 + w1 * (nl - 1);
+    // per item: the same staging, 5 (layer 0) vs 7 column tiles of MFMAs (bf16 pipe: the staging weighs more; 15 : 18
+    // measured best of 12..18 : 18, by 1 us at the headline shape, 3 at V = 64)
+    const int w0 = g->bf16mma ? 15 : 6, w1 = g->bf16mma ? 18 : 7, wsum = w0 + w1 * (nl - 1);
     int begin = 0, maxw = 0;
     for (int l = 0; l < nl; ++l) {
         int cnt = (int)((int64_t)total * (l == 0 ? w0 : w1) / wsum);

@@ -35,7 +35,6 @@ namespace stg {
 
 namespace {
 
-namespace wg3 {
 
 constexpr int C = Cfg::C, P = Cfg::P;
 constexpr int kRec = 96;                        // bytes of a position record: [h | m | l][12 bf16 + 4 pad]
@@ -395,7 +394,6 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 5 : 6) void txp_wgrad_bf16_kerne
         layer<Cfg::P, BF, CH, NW, NIMG>(a, order, order_peds, num_peds, key_start, l, smb, wg, nwg);
 }
 
-}  // namespace wg3
 
 }  // namespace
 
@@ -414,7 +412,7 @@ void wgrad_bf16_geom(WgradGeom *g, const ModelLayout &L, int V) {
     g->waves = bf ? 5 : 10;
     g->nbuf = bf ? 1 : 2;
     const size_t row = (size_t)((Cfg::P * Cfg::P * 9 + Cfg::P + 3) & ~3) * sizeof(float) * g->waves;
-    size_t lds = (size_t)g->nbuf * wg3::kImageBytes;
+    size_t lds = (size_t)g->nbuf * kImageBytes;
     if (lds < row) lds = row;
     g->lds = lds;
 }
@@ -424,10 +422,10 @@ int launch_txp_wgrad_bf16(const WgradArgs &w, const WgradGeom &g, hipStream_t st
     const bool bf = (w.lay.flags & STG_OPT_BF16_STORE) != 0, ch = w.V > kWgradChunkV;
 #define STG_LW3(B, H, NW, NI)                                                                                         \
     do {                                                                                                              \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&wg3::txp_wgrad_bf16_kernel<B, H, NW, NI>),                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&txp_wgrad_bf16_kernel<B, H, NW, NI>),                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);                   \
         if (e != hipSuccess) return hip_fail(e, "txp_wgrad_bf16: hipFuncSetAttribute");                                \
-        hipLaunchKernelGGL((wg3::txp_wgrad_bf16_kernel<B, H, NW, NI>), grid, block, g.lds, st, w, w.order, w.order_peds, w.num_peds,  \
+        hipLaunchKernelGGL((txp_wgrad_bf16_kernel<B, H, NW, NI>), grid, block, g.lds, st, w, w.order, w.order_peds, w.num_peds,  \
                            w.key_start);                                                                              \
     } while (0)
 #define STG_LW3V(NW, NI)                                                                                              \

@@ -141,12 +141,13 @@ int main(int argc, char **argv) {
         WgradGeom g{};
         if (!wgrad_geom(L, N, V, &g)) return 1;         // the library's split of the chip over the layers ...
         g.waves = nws[v]; g.nbuf = nis[v];              // ... for this workgroup shape
-        g.lds = (size_t)nis[v] * wg3::kImageBytes;
+        g.lds = (size_t)nis[v] * kImageBytes;
         {
-            const int per_cu = (int)((size_t)kLdsBytes / g.lds), total = kNumCU * per_cu, wsum = 7 + 9 * (nl - 1);
+            const int w0 = getenv("K2_W0") ? atoi(getenv("K2_W0")) : 15, w1 = 18;      // split of the chip over the layers (halves of a tile)
+            const int per_cu = (int)((size_t)kLdsBytes / g.lds), total = kNumCU * per_cu, wsum = w0 + w1 * (nl - 1);
             int begin = 0, maxw = 0;
             for (int l = 0; l < nl; ++l) {
-                int cnt = total * (l == 0 ? 7 : 9) / wsum;
+                int cnt = total * (l == 0 ? w0 : w1) / wsum;
                 if (cnt > N * wgrad_chunks(V)) cnt = N * wgrad_chunks(V);
                 g.wg_begin[l] = begin; begin += cnt; if (cnt > maxw) maxw = cnt;
             }
