@@ -165,8 +165,8 @@ int main(int argc, char **argv) {
                worst / refmax, wi, got[wi], ref[wi]);
     }
     if (N <= 64) {
-        // fp64 host sum of layer 1 (c_in = 12) and layer 0 (c_in = 8)
-        for (int l : {0, 1}) {
+        // fp64 host sum of every layer (layer 0: c_in = 8, the others 12)
+        for (int l = 0; l < nl; ++l) {
             const int cin = l == 0 ? Cfg::T : Cfg::P;
             std::vector<double> W((size_t)12 * cin * 9 + 12, 0.0);
             for (int n = 0; n < N; ++n) {
