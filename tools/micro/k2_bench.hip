@@ -144,7 +144,8 @@ int main(int argc, char **argv) {
         g.lds = (size_t)nis[v] * kImageBytes;
         {
             const int w0 = getenv("K2_W0") ? atoi(getenv("K2_W0")) : 15, w1 = 18;      // split of the chip over the layers (halves of a tile)
-            const int per_cu = (int)((size_t)kLdsBytes / g.lds), total = kNumCU * per_cu, wsum = w0 + w1 * (nl - 1);
+            const int per_cu = getenv("K2_PERCU") ? atoi(getenv("K2_PERCU")) : (int)((size_t)kLdsBytes / g.lds);
+            const int total = kNumCU * per_cu, wsum = w0 + w1 * (nl - 1);
             int begin = 0, maxw = 0;
             for (int l = 0; l < nl; ++l) {
                 int cnt = total * (l == 0 ? w0 : w1) / wsum;
