@@ -142,6 +142,110 @@ __global__ __launch_bounds__(256) void adj_build_kernel(
     }
 }
 
+// One workgroup per (scene, time step): the form for SMALL batches (a real ETH/UCY group is 512 scenes of 2..57 pedestrians
+// padded to 60: 512 workgroups of the per-scene kernel are two per CU, and each walks its 8 x 60 rows alone -- 29 us for
+// 59 MB, the latency of one workgroup).  Same operations in the same order as adj_build_kernel: bitwise identical output.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void adj_build_tile_kernel(
+    const float *__restrict__ rel, int64_t rel_sn, int64_t rel_sv, int64_t rel_sc, int64_t rel_st,
+    const int32_t *__restrict__ num_peds, int V, int T, int normalize,
+    float *__restrict__ nodes, float *__restrict__ adj) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *px = sm, *py = px + V, *dinv = py + V, *diag = dinv + V;      // [V] each (this time step)
+    const int n = blockIdx.x / T, t = blockIdx.x - n * T, tid = threadIdx.x;
+    int vi = num_peds ? num_peds[n] : V;
+    vi = vi < 0 ? 0 : (vi > V ? V : vi);
+    const float *r = rel + n * rel_sn + t * rel_st;
+    for (int e = tid; e < 2 * V; e += blockDim.x) {
+        const int c = e & 1, h = e >> 1;
+        (c ? py : px)[h] = h < vi ? r[h * rel_sv + c * rel_sc] : 0.f;
+    }
+    __syncthreads();
+    if (nodes) {
+        float2 *o = reinterpret_cast<float2 *>(nodes + ((int64_t)n * T + t) * V * 2);
+        for (int e = tid; e < V; e += blockDim.x) o[e] = make_float2(px[e], py[e]);
+    }
+    if (normalize) {
+        for (int h = tid; h < vi; h += blockDim.x) {
+            const float hx = px[h], hy = py[h];
+            double acc = 1.0;
+            int k = 0;
+            if (VEC4) {
+                for (; k + 4 <= vi; k += 4) {
+                    const float4 x4 = *reinterpret_cast<const float4 *>(px + k);
+                    const float4 y4 = *reinterpret_cast<const float4 *>(py + k);
+                    const float a0 = inv_dist(hx, hy, x4.x, y4.x), a1 = inv_dist(hx, hy, x4.y, y4.y);
+                    const float a2 = inv_dist(hx, hy, x4.z, y4.z), a3 = inv_dist(hx, hy, x4.w, y4.w);
+                    acc += (double)(k + 0 != h ? a0 : 0.f);
+                    acc += (double)(k + 1 != h ? a1 : 0.f);
+                    acc += (double)(k + 2 != h ? a2 : 0.f);
+                    acc += (double)(k + 3 != h ? a3 : 0.f);
+                }
+            }
+            for (; k < vi; ++k)
+                if (k != h) acc += (double)inv_dist(hx, hy, px[k], py[k]);
+            dinv[h] = (float)(1.0 / sqrt(acc));
+            diag[h] = (float)(acc - 1.0);
+        }
+        __syncthreads();
+    }
+    float *out = adj + ((int64_t)n * T + t) * V * V;
+    if (VEC4) {
+        const int v4 = V >> 2;
+        int cw = 1;
+        while (cw < v4) cw <<= 1;
+        if (cw > (int)blockDim.x) cw = blockDim.x;
+        const int rows_per_pass = blockDim.x / cw, r0 = tid / cw, c0 = tid - r0 * cw;
+        for (int h = r0; h < V; h += rows_per_pass) {
+            for (int c = c0; c < v4; c += cw) {
+                const int k0 = c << 2;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (h < vi) {
+                    const float hx = px[h], hy = py[h];
+                    const float dh = normalize ? dinv[h] : 1.f;
+                    float vals[4];
+                    const float4 x4 = *reinterpret_cast<const float4 *>(px + k0);
+                    const float4 y4 = *reinterpret_cast<const float4 *>(py + k0);
+                    const float4 d4 = normalize ? *reinterpret_cast<const float4 *>(dinv + k0) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
+                    const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const float dg = (normalize && h >= k0 && h < k0 + 4) ? diag[h] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = k0 + j;
+                        float v = 0.f;
+                        if (k < vi) {
+                            if (k == h)
+                                v = normalize ? dg * (dh * dh) : 1.f;
+                            else {
+                                const float a = inv_dist(hx, hy, xs[j], ys[j]);
+                                v = normalize ? -(a * (dh * ds[j])) : a;
+                            }
+                        }
+                        vals[j] = v;
+                    }
+                    o = make_float4(vals[0], vals[1], vals[2], vals[3]);
+                }
+                reinterpret_cast<float4 *>(out)[h * v4 + c] = o;
+            }
+        }
+    } else {
+        for (int e = tid; e < V * V; e += blockDim.x) {
+            const int h = e / V, k = e - h * V;
+            float v = 0.f;
+            if (h < vi && k < vi) {
+                if (k == h)
+                    v = normalize ? diag[h] * (dinv[h] * dinv[h]) : 1.f;
+                else {
+                    const float a = inv_dist(px[h], py[h], px[k], py[k]);
+                    v = normalize ? -(a * (dinv[h] * dinv[k])) : a;
+                }
+            }
+            out[e] = v;
+        }
+    }
+}
+
 // V == 32 fast path (the north-star crowd size): thread (t, h) owns ROW h of tile t.  It computes the row's 32
 // weights once, keeps them in registers across the degree barrier (the generic kernel recomputes them), scales them
 // and parks the row in an LDS tile (16-byte chunks XOR-swizzled by the row index: conflict-free although every lane
@@ -258,6 +362,20 @@ extern "C" int stg_adj_build(const float *rel, int64_t rel_sn, int64_t rel_sv, i
             STG_LAUNCH_CHECK("stg_adj_build");
             return STG_OK;
         }
+    }
+    // small batches: a workgroup per (scene, time step) -- T times the workgroups -- while the per-scene form would leave most of
+    // the chip's workgroup slots empty (measured on a real eth/train group, 512 scenes padded to 60: 29 us per-scene)
+    if (N < 1024) {
+        const dim3 tgrid((unsigned)(N * T));
+        const size_t tlds = (size_t)4 * V * sizeof(float);
+        if (vec4)
+            hipLaunchKernelGGL(stg::adj_build_tile_kernel<true>, tgrid, block, tlds, stg::as_stream(stream), rel, rel_sn,
+                               rel_sv, rel_sc, rel_st, num_peds, V, T, normalize, nodes, adj);
+        else
+            hipLaunchKernelGGL(stg::adj_build_tile_kernel<false>, tgrid, block, tlds, stg::as_stream(stream), rel, rel_sn,
+                               rel_sv, rel_sc, rel_st, num_peds, V, T, normalize, nodes, adj);
+        STG_LAUNCH_CHECK("stg_adj_build");
+        return STG_OK;
     }
     if (vec4)
         hipLaunchKernelGGL(stg::adj_build_kernel<true>, grid, block, lds, stg::as_stream(stream), rel, rel_sn,

@@ -145,6 +145,18 @@ def test_adj_build_batched_ragged(dev):
         assert torch.equal(a_a, a_b[:, :, :32, :32]) and torch.equal(n_a, n_b[:, :, :32])
     assert _maxdiff(a_a[3].cpu().numpy() * 0 + ops.adj_build(rel32[3:4, :32].contiguous().to(dev))[1][0].cpu().numpy(),
                     g["lap_32"]) < 1e-6
+    # small batches (fewer than 1024 scenes) run a workgroup per (scene, time step), large ones one per scene: bitwise equal
+    # (the ragged batch above tiled to 1024 scenes), normalised and raw, 16-byte and scalar stores (V = 60 / 59)
+    for vpad in (60, 59):
+        relp = torch.zeros(len(vs), vpad, 2, 8)
+        relp[:, :min(vpad, vmax)] = rel[:, :min(vpad, vmax)]
+        big = relp.repeat(1024 // len(vs) + 1, 1, 1, 1)[:1024].contiguous().to(dev)
+        vbig = (vs * (1024 // len(vs) + 1))[:1024]
+        for norm in (True, False):
+            n_s, a_s = ops.adj_build(relp.to(dev), num_peds=vs, normalize=norm)
+            n_l, a_l = ops.adj_build(big, num_peds=vbig, normalize=norm)
+            assert torch.equal(a_s, a_l[:len(vs)]) and torch.equal(n_s, n_l[:len(vs)])
+            assert torch.equal(a_l[:len(vs)], a_l[1022 - 1022 % len(vs) - len(vs):1022 - 1022 % len(vs)])
 
 
 # ------------------------------------------------------------------------------------------
