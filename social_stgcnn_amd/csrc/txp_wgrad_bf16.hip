@@ -87,13 +87,14 @@ __device__ __forceinline__ f32x4 mma(const u32x4 &a, const u32x4 &b, const f32x4
 }
 // the six products of one column tile, accumulated IN PLACE: as an asm statement with a read-write accumulator (through the
 // builtin hipcc renamed the accumulators from tile to tile inside the item loop -- copies at the loop edges, 21 spilled
-// registers).  hipcc's hazard recognizer cannot see inside the statement, so it carries its own wait states: s_nop 1 in
-// front (a VALU write of an accumulator / operand register needs two wait states before an MFMA reads it -- found the hard
+// registers).  hipcc's hazard recognizer cannot see inside the statement, so it carries its own wait states: s_nop 3 in
+// front (a VALU write of an accumulator / operand register needs wait states before an MFMA reads it: two were enough in
+// every arrangement measured, four are issued -- found the hard
 // way: a peeled first iteration put an accumulator's zero-initialising v_mov right in front of the statement and the sums
 // were garbage) and s_nop 7 behind (MFMA result -> VALU / LDS read: 4 passes + 3).
 __device__ __forceinline__ void mma6(const u32x4 &zh, const u32x4 &zm, const u32x4 &zl, const Op &a, f32x4 &acc) {
     const u32x4 ah = cat(a.h), am = cat(a.m), al = cat(a.l);
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\t"
+    asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\t"
                  "v_mfma_f32_16x16x32_bf16 %0, %2, %4, %0\n\t"
                  "v_mfma_f32_16x16x32_bf16 %0, %1, %5, %0\n\t"
                  "v_mfma_f32_16x16x32_bf16 %0, %2, %5, %0\n\t"
@@ -104,7 +105,7 @@ __device__ __forceinline__ void mma6(const u32x4 &zh, const u32x4 &zm, const u32
                  : "v"(zh), "v"(zm), "v"(zl), "v"(ah), "v"(am), "v"(al));
 }
 __device__ __forceinline__ void mma1(const u32x4 &zh, const u32x4 &ah, f32x4 &acc) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7" : "+v"(acc) : "v"(zh), "v"(ah));
+    asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7" : "+v"(acc) : "v"(zh), "v"(ah));
 }
 template <bool BF> struct StageType { typedef f32x4 type; };
 template <> struct StageType<true> { typedef u32x2 type; };
