@@ -89,13 +89,19 @@ __device__ __forceinline__ void split_pack4(const f32x4 &v, uint2 &ph, uint2 &pm
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     f32x2 h[2], m[2], l[2];
+    // a - b on a float pair, as the instruction (hipcc packs only one of the two subtractions by itself)
+    auto pk_sub = [](const f32x2 &a_, const f32x2 &b_) -> f32x2 {
+        f32x2 d;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a_), "v"(b_));
+        return d;
+    };
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const f32x2 x = {v[2 * r], v[2 * r + 1]};
         h[r] = __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, x) & 0xffff0000u);
-        const f32x2 rem = x - h[r];
+        const f32x2 rem = pk_sub(x, h[r]);
         m[r] = __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, rem) & 0xffff0000u);
-        l[r] = rem - m[r];
+        l[r] = pk_sub(rem, m[r]);
     }
     ph = make_uint2(pack_top(h[0][0], h[0][1]), pack_top(h[1][0], h[1][1]));
     pm = make_uint2(pack_top(m[0][0], m[0][1]), pack_top(m[1][0], m[1][1]));
