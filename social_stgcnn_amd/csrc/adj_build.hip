@@ -349,7 +349,7 @@ extern "C" int stg_adj_build(const float *rel, int64_t rel_sn, int64_t rel_sv, i
     STG_REQUIRE(lds <= stg::kLdsBytes, STG_ELDS, "stg_adj_build: V=%d exceeds the LDS budget", V);
     const dim3 grid((unsigned)N), block(256);
     const bool vec4 = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(adj) & 15) == 0);
-    if (vec4 && V == 32 && T * V <= 1024) {
+    if (vec4 && V == 32 && T * V <= 1024 && !stg::diag_env("STG_ADJ_TILE", 0)) {
         const size_t lds32 = ((size_t)3 * T * V + (size_t)T * V * V) * sizeof(float);
         if (lds32 <= (size_t)stg::kLdsBytes) {
             if (lds32 > 48 * 1024) {
@@ -365,7 +365,7 @@ extern "C" int stg_adj_build(const float *rel, int64_t rel_sn, int64_t rel_sv, i
     }
     // small batches: a workgroup per (scene, time step) -- T times the workgroups -- while the per-scene form would leave most of
     // the chip's workgroup slots empty (measured on a real eth/train group, 512 scenes padded to 60: 29 us per-scene)
-    if (N < 1024) {
+    if (N < 1024 || stg::diag_env("STG_ADJ_TILE", 0)) {
         const dim3 tgrid((unsigned)(N * T));
         const size_t tlds = (size_t)4 * V * sizeof(float);
         if (vec4)
