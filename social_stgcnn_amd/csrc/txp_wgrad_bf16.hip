@@ -285,6 +285,7 @@ __device__ __forceinline__ void layer(const WgradArgs &a, const int32_t *__restr
         if (!it.valid || STG_SKIP(a, 128)) return;
         if (32 * ks >= C * it.vc) return;
         if (it.vc != vc_cur) kslots(it.vc);
+        __builtin_amdgcn_s_setprio(2);
         Op z, x0;
         u32x4 zh, zm = u32x4{0u, 0u, 0u, 0u}, zl = zm;
         if constexpr (BF) {
@@ -307,6 +308,7 @@ __device__ __forceinline__ void layer(const WgradArgs &a, const int32_t *__restr
             }
         }
         (void)zm; (void)zl;
+        __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- constants of the images: everything zero (the plane's border rows stay so), the ones record --------------------
