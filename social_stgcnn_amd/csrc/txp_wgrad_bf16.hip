@@ -21,8 +21,10 @@
 //    bias in the record's pad quad were measured too: 55.6 us against 47.4, the MFMA count decides.)
 //  * FIXED IMAGE GEOMETRY: the LDS image of a work item always has rows of 34 (plane) / 32 (dz) records, whatever the
 //    crowd size: every LDS address of the staging tasks and the border rows are loop constants, written / computed once.
-//  * A wave owns a K-step (32 positions) and ALL column tiles: the dz operand is fetched once per K-step.
-//    5-wave workgroups with ONE image each, four per CU (two barriers per item), or 10-wave / two-image ones.
+//  * Two workgroup shapes: 10 waves (two share a K-step of 32 positions and split its column tiles) with two images, two
+//    per CU, one barrier per item -- fp32 storage; 5 waves (a wave owns a K-step and ALL column tiles: the dz operand is
+//    fetched once per K-step) with ONE image, four per CU, two barriers per item -- bf16 storage.  The MFMA phase runs at
+//    raised wave priority (s_setprio): the waves past the barrier win the issue slots over the ones still splitting.
 //  * The six MFMAs of a tile accumulate IN PLACE (one asm statement with a read-write accumulator).  Reading tile t+1's
 //    operand in front of tile t's MFMAs (a second operand set) was measured: it spills at the 80 registers two 10-wave
 //    workgroups per CU allow (54.7 us against 47.4).
@@ -34,7 +36,6 @@
 namespace stg {
 
 namespace {
-
 
 constexpr int C = Cfg::C, P = Cfg::P;
 constexpr int kRec = 96;                        // bytes of a position record: [h | m | l][12 bf16 + 4 pad]

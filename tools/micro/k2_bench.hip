@@ -135,7 +135,7 @@ int main(int argc, char **argv) {
     for (double v : ref) refmax = std::fmax(refmax, std::fabs(v));
     const int nvar = 2;
     const int nws[nvar] = {5, 10}, nis[nvar] = {1, 2};
-    const char *names[nvar] = {"v3 5w 1img", "v3 10w 2img"};
+    const char *names[nvar] = {"tree 5w 1img", "tree 10w 2img"};
     for (int v = 0; v < nvar; ++v) {
         if (getenv("K2_ONLY") && atoi(getenv("K2_ONLY")) != v) continue;
         WgradGeom g{};
