@@ -251,6 +251,10 @@ __global__ __launch_bounds__(256) void adj_build_tile_kernel(
 // and parks the row in an LDS tile (16-byte chunks XOR-swizzled by the row index: conflict-free although every lane
 // writes a different row); the workgroup then streams the T tiles to HBM with coalesced 16-byte stores.
 // Same operations in the same order as adj_build_kernel: bitwise identical output.
+// ROWS: rows of the LDS tile = rows streamed out per phase.  256: the whole pass in one phase (35 KB of LDS, four workgroups per CU);
+// 128: two phases (19 KB, eight per CU) -- the better choice once the batch no longer fits the chip at four per CU (same
+// box, 537 MB of adjacency: 3.35 -> 3.78 TB/s; at 2048 scenes, where every workgroup is resident either way, 2 % slower).
+template <int ROWS>
 __global__ __launch_bounds__(256) void adj_build_rows32_kernel(
     const float *__restrict__ rel, int64_t rel_sn, int64_t rel_sv, int64_t rel_sc, int64_t rel_st,
     const int32_t *__restrict__ num_peds, int T, int normalize, float *__restrict__ nodes,
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void adj_build_rows32_kernel(
     float *px = sm;                // [T][V]
     float *py = px + T * V;        // [T][V]
     float *dinv = py + T * V;      // [T][V]  1/sqrt(d)
-    float *tile = dinv + T * V;    // [T*V rows][V], chunk j of row e at chunk (j ^ (e & 7))
+    float *tile = dinv + T * V;    // [ROWS rows][V], chunk j of row e at chunk (j ^ (e & 7))
     const int n = blockIdx.x, tid = threadIdx.x;
     int vi = num_peds ? num_peds[n] : V;
     vi = vi < 0 ? 0 : (vi > V ? V : vi);
@@ -303,36 +307,42 @@ __global__ __launch_bounds__(256) void adj_build_rows32_kernel(
         const float dg = (float)(acc - 1.0);
         if (normalize && live_row) dinv[ec] = dh;
         __syncthreads();
-        if (live_row) {
-            const float *qd = dinv + t * V;
-            float4 *trow = reinterpret_cast<float4 *>(tile + ec * V);
-#pragma unroll
-            for (int k4 = 0; k4 < V / 4; ++k4) {
-                float vals[4];
-                const float4 d4 = normalize ? *reinterpret_cast<const float4 *>(qd + 4 * k4) : make_float4(1.f, 1.f, 1.f, 1.f);
-                const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = 4 * k4 + j;
-                    float v = 0.f;
-                    if (h < vi && k < vi) {
-                        if (k == h) v = normalize ? dg * (dh * dh) : 1.f;
-                        else v = normalize ? -(a[k] * (dh * ds[j])) : a[k];
-                    }
-                    vals[j] = v;
-                }
-                trow[k4 ^ (ec & 7)] = make_float4(vals[0], vals[1], vals[2], vals[3]);
-            }
-        }
-        __syncthreads();
-        // coalesced copy-out of the rows [e0, e0 + blockDim.x): 8 chunks per row, un-swizzled on the way
+        // the scaled rows leave through the LDS tile, ROWS at a time: the threads of a phase park their rows, the whole
+        // workgroup streams them out
+        const float *qd = dinv + t * V;
         float4 *out4 = reinterpret_cast<float4 *>(adj + (int64_t)n * T * V * V);
-        const int rows = (T * V - e0) < (int)blockDim.x ? (T * V - e0) : (int)blockDim.x;
-        for (int f = tid; f < rows * (V / 4); f += blockDim.x) {
-            const int row = e0 + (f >> 3), p = f & 7;
-            out4[row * (V / 4) + (p ^ (row & 7))] = reinterpret_cast<const float4 *>(tile + row * V)[p];
+#pragma unroll
+        for (int half = 0; half < 256 / ROWS; ++half) {
+            const int r0 = e0 + ROWS * half;                                   // first row of this phase
+            if (live_row && tid / ROWS == half) {
+                float4 *trow = reinterpret_cast<float4 *>(tile + (tid & (ROWS - 1)) * V);
+#pragma unroll
+                for (int k4 = 0; k4 < V / 4; ++k4) {
+                    float vals[4];
+                    const float4 d4 = normalize ? *reinterpret_cast<const float4 *>(qd + 4 * k4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 4 * k4 + j;
+                        float v = 0.f;
+                        if (h < vi && k < vi) {
+                            if (k == h) v = normalize ? dg * (dh * dh) : 1.f;
+                            else v = normalize ? -(a[k] * (dh * ds[j])) : a[k];
+                        }
+                        vals[j] = v;
+                    }
+                    trow[k4 ^ (ec & 7)] = make_float4(vals[0], vals[1], vals[2], vals[3]);
+                }
+            }
+            __syncthreads();
+            // coalesced copy-out of the rows [r0, r0 + ROWS): 8 chunks per row, un-swizzled on the way
+            const int rows = (T * V - r0) < ROWS ? (T * V - r0) : ROWS;
+            for (int f = tid; f < rows * (V / 4); f += blockDim.x) {
+                const int lr = f >> 3, row = r0 + lr, p = f & 7;
+                out4[row * (V / 4) + (p ^ (row & 7))] = reinterpret_cast<const float4 *>(tile + lr * V)[p];
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -350,15 +360,21 @@ extern "C" int stg_adj_build(const float *rel, int64_t rel_sn, int64_t rel_sv, i
     const dim3 grid((unsigned)N), block(256);
     const bool vec4 = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(adj) & 15) == 0);
     if (vec4 && V == 32 && T * V <= 1024 && !stg::diag_env("STG_ADJ_TILE", 0)) {
-        const size_t lds32 = ((size_t)3 * T * V + (size_t)T * V * V) * sizeof(float);
+        const int rows = N > 2048 ? 128 : 256;              // (rows of the LDS tile: see the kernel)
+        const size_t lds32 = ((size_t)3 * T * V + (size_t)rows * V) * sizeof(float);
         if (lds32 <= (size_t)stg::kLdsBytes) {
-            if (lds32 > 48 * 1024) {
-                hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&stg::adj_build_rows32_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
-                if (e_ != hipSuccess) return stg::hip_fail(e_, "stg_adj_build: hipFuncSetAttribute");
+            if (rows == 128) {
+                hipLaunchKernelGGL(stg::adj_build_rows32_kernel<128>, grid, block, lds32, stg::as_stream(stream), rel, rel_sn,
+                                   rel_sv, rel_sc, rel_st, num_peds, T, normalize, nodes, adj);
+            } else {
+                if (lds32 > 48 * 1024) {
+                    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&stg::adj_build_rows32_kernel<256>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+                    if (e_ != hipSuccess) return stg::hip_fail(e_, "stg_adj_build: hipFuncSetAttribute");
+                }
+                hipLaunchKernelGGL(stg::adj_build_rows32_kernel<256>, grid, block, lds32, stg::as_stream(stream), rel, rel_sn,
+                                   rel_sv, rel_sc, rel_st, num_peds, T, normalize, nodes, adj);
             }
-            hipLaunchKernelGGL(stg::adj_build_rows32_kernel, grid, block, lds32, stg::as_stream(stream), rel, rel_sn,
-                               rel_sv, rel_sc, rel_st, num_peds, T, normalize, nodes, adj);
             STG_LAUNCH_CHECK("stg_adj_build");
             return STG_OK;
         }

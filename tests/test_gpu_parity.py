@@ -145,6 +145,14 @@ def test_adj_build_batched_ragged(dev):
         assert torch.equal(a_a, a_b[:, :, :32, :32]) and torch.equal(n_a, n_b[:, :, :32])
     assert _maxdiff(a_a[3].cpu().numpy() * 0 + ops.adj_build(rel32[3:4, :32].contiguous().to(dev))[1][0].cpu().numpy(),
                     g["lap_32"]) < 1e-6
+    # more than 2048 scenes of 32 slots leave through a half-size LDS tile (two phases): bitwise equal to the one-phase kernel
+    big32 = rel32[:, :32].repeat(2056 // len(vs32) + 1, 1, 1, 1)[:2056].contiguous().to(dev)
+    vbig32 = (vs32 * (2056 // len(vs32) + 1))[:2056]
+    for norm in (True, False):
+        n_s, a_s = ops.adj_build(rel32[:, :32].contiguous().to(dev), num_peds=vs32, normalize=norm)
+        n_l, a_l = ops.adj_build(big32, num_peds=vbig32, normalize=norm)
+        assert torch.equal(a_s, a_l[:len(vs32)]) and torch.equal(n_s, n_l[:len(vs32)])
+        assert torch.equal(a_l[:len(vs32)], a_l[2048:2048 + len(vs32)])
     # small batches (fewer than 1024 scenes) run a workgroup per (scene, time step), large ones one per scene: bitwise equal
     # (the ragged batch above tiled to 1024 scenes), normalised and raw, 16-byte and scalar stores (V = 60 / 59)
     for vpad in (60, 59):
