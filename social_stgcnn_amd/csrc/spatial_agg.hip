@@ -81,6 +81,84 @@ __global__ __launch_bounds__(256) void spatial_agg_fwd_kernel(
     }
 }
 
+// forward, all 256 lanes streaming, for V = 4 * LPR (used at V = 32): a lane owns a 16-byte piece of the OUTPUT
+// row (t, w0..w0+3) for a QUARTER of the adjacency rows v -- its LPR loads all in flight -- and the four quarters of a piece sit
+// four lanes apart in a 16-lane DPP row, so their partial sums meet in two rotate-adds (pure VALU).  (The strip form above
+// leaves three of four waves idle at V = 32: T * V / 4 = 64 strips.)
+template <int LPR>
+__global__ __launch_bounds__(256) void spatial_agg_fwd_quarters_kernel(
+    const float *__restrict__ x, int64_t x_sn, int64_t x_sc, int64_t x_st, int64_t x_sv,
+    const float *__restrict__ adj, int64_t a_sn, const int32_t *__restrict__ num_peds,
+    int C, int T, float *__restrict__ y) {
+    constexpr int V = 4 * LPR, RPL = V / 4;                          // rows per lane: a quarter of the tile
+    constexpr int TL = 64 / (4 * LPR);                               // time steps per wave and pass
+    extern __shared__ __attribute__((aligned(16))) float xs[];       // [C][T][V], padded rows zeroed
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int vi = num_peds ? num_peds[n] : V;
+    vi = vi < 0 ? 0 : (vi > V ? V : vi);
+    const float *xn = x + n * x_sn;
+    for (int e = tid; e < C * T * V; e += 256) {
+        const int v = e % V, ct = e / V, t = ct % T, c = ct / T;
+        xs[e] = v < vi ? xn[c * x_sc + t * x_st + v * x_sv] : 0.f;
+    }
+    __syncthreads();
+    // lane = [piece low 2 bits | quarter (2 bits) | piece high bits | time step of the wave]
+    const int plo = lane & 3, q = (lane >> 2) & 3, rest = lane >> 4;
+    constexpr int PHB = LPR / 4;                                     // values of the piece's high part
+    const int piece = plo | ((rest % PHB) << 2), tl = rest / PHB, w0 = 4 * piece;
+    const float *an = adj + n * a_sn;
+    float *yn = y + (int64_t)n * C * T * V;
+    for (int t0 = 0; t0 < T; t0 += 4 * TL) {
+        const int t = t0 + wave * TL + tl;
+        const bool live = t < T;
+        float4 a[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int v = q * RPL + i;
+            a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live && v < vi) a[i] = *reinterpret_cast<const float4 *>(an + ((int64_t)t * V + v) * V + w0);
+        }
+        for (int c0 = 0; c0 < C; c0 += kAggMaxC) {
+            const int cn = (C - c0) < kAggMaxC ? (C - c0) : kAggMaxC;
+            float4 acc[kAggMaxC];
+#pragma unroll
+            for (int c = 0; c < kAggMaxC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *xt = xs + ((c0 * T) + (live ? t : 0)) * V + q * RPL;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+#pragma unroll
+                for (int c = 0; c < kAggMaxC; ++c) {
+                    if (c < cn) {
+                        const float xv = xt[c * T * V + i];
+                        acc[c].x = fmaf(xv, a[i].x, acc[c].x);
+                        acc[c].y = fmaf(xv, a[i].y, acc[c].y);
+                        acc[c].z = fmaf(xv, a[i].z, acc[c].z);
+                        acc[c].w = fmaf(xv, a[i].w, acc[c].w);
+                    }
+                }
+            }
+#define STG_ROR_ADD(v_, ctrl) v_ += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v_), (ctrl), 0xf, 0xf, false))
+#pragma unroll
+            for (int c = 0; c < kAggMaxC; ++c) {
+                if (c < cn) {
+                    // the four quarters: lanes l, l + 4, l + 8, l + 12 of the 16-lane row (row_ror:4, then row_ror:8)
+                    STG_ROR_ADD(acc[c].x, 0x124); STG_ROR_ADD(acc[c].y, 0x124); STG_ROR_ADD(acc[c].z, 0x124); STG_ROR_ADD(acc[c].w, 0x124);
+                    STG_ROR_ADD(acc[c].x, 0x128); STG_ROR_ADD(acc[c].y, 0x128); STG_ROR_ADD(acc[c].z, 0x128); STG_ROR_ADD(acc[c].w, 0x128);
+                    if (live && q == 0) {
+                        float4 r;
+                        r.x = (w0 + 0 < vi) ? acc[c].x : 0.f;
+                        r.y = (w0 + 1 < vi) ? acc[c].y : 0.f;
+                        r.z = (w0 + 2 < vi) ? acc[c].z : 0.f;
+                        r.w = (w0 + 3 < vi) ? acc[c].w : 0.f;
+                        *reinterpret_cast<float4 *>(yn + ((int64_t)(c0 + c) * T + t) * V + w0) = r;
+                    }
+                }
+            }
+#undef STG_ROR_ADD
+        }
+    }
+}
+
 // backward: one workgroup per scene.  dy[n] (C*T*V floats) is staged in LDS; a lane owns one ROW (t, v) of the adjacency and
 // streams it from HBM with 16-byte loads -- a wave reads 64 consecutive rows, every 128-byte line is consumed by consecutive
 // instructions of the same lane (L1 hits) -- while dy[c][t][w..w+3] comes from LDS as a broadcast read (all lanes of a
@@ -260,7 +338,12 @@ int stg_spatial_agg_fwd(const float *x, int64_t x_sn, int64_t x_sc, int64_t x_st
     STG_REQUIRE(lds <= stg::kLdsBytes, STG_ELDS, "stg_spatial_agg_fwd: C*T*V=%d floats exceed LDS", C * T * V);
     const bool vec4 = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(adj) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (a_sn % 4 == 0);
-    if (vec4)
+    if (vec4 && V == 32 && lds <= 64 * 1024) {
+        // (same box, 537 MB working set: 4.07 -> 4.82 TB/s; at V = 64 the quarters form -- 16 loads in flight per lane -- loses to
+        // the strip form, 3.85 against 4.15, at V = 16 they are equal: only instantiated for 32)
+        hipLaunchKernelGGL(stg::spatial_agg_fwd_quarters_kernel<8>, dim3(N), dim3(256), lds, stg::as_stream(stream), x, x_sn,
+                           x_sc, x_st, x_sv, adj, a_sn, num_peds, C, T, y);
+    } else if (vec4)
         hipLaunchKernelGGL(stg::spatial_agg_fwd_kernel<4>, dim3(N), dim3(256), lds, stg::as_stream(stream), x,
                            x_sn, x_sc, x_st, x_sv, adj, a_sn, num_peds, C, T, V, y);
     else
