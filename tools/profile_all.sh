@@ -18,15 +18,6 @@ export PYTHONDONTWRITEBYTECODE=1 TMPDIR=/tmp
 OUT=gpurun_out/profiles_r03
 rm -rf $OUT; mkdir -p $OUT
 run() { timeout -k 10 600 "$@"; }
-run python bench.py > $OUT/r03_bench.json.log 2>/dev/null; echo "bench $?"
-run python bench.py --dataset eth-train --batch 512 --no-cpu-baseline > $OUT/r03_bench_eth_train_512.json.log 2>/dev/null; echo "eth $?"
-run python bench.py --dtype bf16 --no-cpu-baseline > $OUT/r03_bench_bf16.json.log 2>/dev/null; echo "bf16 $?"
-run python bench.py --dataset all-train --batch 2048 --no-cpu-baseline > $OUT/r03_bench_all_train_2048.json.log 2>/dev/null; echo "all-train $?"
-run python bench.py --dataset all-train --batch 2048 --dtype bf16 --no-cpu-baseline > $OUT/r03_bench_all_train_2048_bf16.json.log 2>/dev/null; echo "all-train bf16 $?"
-run python bench.py --peds 64 --no-cpu-baseline --kernels-only > $OUT/r03_bench_v64.json.log 2>/dev/null; echo "v64 $?"
-run python bench.py --peds 128 --batch 4096 --no-cpu-baseline --kernels-only > $OUT/r03_bench_v128_4096.json.log 2>/dev/null; echo "v128 $?"
-STG_DIST_BACKEND=gloo run python bench.py --gpus 2 --no-cpu-baseline --no-extras --steps 20 --repeats 10 > $OUT/r03_bench_gloo2.json.log 2>/dev/null; echo "gloo2 $?"
-TAG=profiles_sweep tools/gpu.sh sweep > /dev/null; cp gpurun_out/profiles_sweep.sweep.log $OUT/r03_sweep.log
 # kernel stats / HBM traffic (separate PMC passes over eager steps, counters are per dispatch) / SQ counters of a configuration
 profile_cfg() {    # $1 = file prefix, rest = bench.py arguments
   pre=$1; shift
@@ -75,6 +66,17 @@ PY
   done
 }
 profile_cfg r03_
+# the bench lines quote roofline.traffic from profiles/r03_pmc_traffic.json while it matches the kernel sources: this visit's file first
+cp $OUT/r03_pmc_traffic.json profiles/r03_pmc_traffic.json
+run python bench.py > $OUT/r03_bench.json.log 2>/dev/null; echo "bench $?"
+run python bench.py --dataset eth-train --batch 512 --no-cpu-baseline > $OUT/r03_bench_eth_train_512.json.log 2>/dev/null; echo "eth $?"
+run python bench.py --dtype bf16 --no-cpu-baseline > $OUT/r03_bench_bf16.json.log 2>/dev/null; echo "bf16 $?"
+run python bench.py --dataset all-train --batch 2048 --no-cpu-baseline > $OUT/r03_bench_all_train_2048.json.log 2>/dev/null; echo "all-train $?"
+run python bench.py --dataset all-train --batch 2048 --dtype bf16 --no-cpu-baseline > $OUT/r03_bench_all_train_2048_bf16.json.log 2>/dev/null; echo "all-train bf16 $?"
+run python bench.py --peds 64 --no-cpu-baseline --kernels-only > $OUT/r03_bench_v64.json.log 2>/dev/null; echo "v64 $?"
+run python bench.py --peds 128 --batch 4096 --no-cpu-baseline --kernels-only > $OUT/r03_bench_v128_4096.json.log 2>/dev/null; echo "v128 $?"
+STG_DIST_BACKEND=gloo run python bench.py --gpus 2 --no-cpu-baseline --no-extras --steps 20 --repeats 10 > $OUT/r03_bench_gloo2.json.log 2>/dev/null; echo "gloo2 $?"
+TAG=profiles_sweep tools/gpu.sh sweep > /dev/null; cp gpurun_out/profiles_sweep.sweep.log $OUT/r03_sweep.log
 profile_cfg r03_team_eth512_ --dataset eth-train --batch 512
 profile_cfg r03_team_v128_4096_ --peds 128 --batch 4096
 ls -la $OUT
